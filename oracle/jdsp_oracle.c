@@ -1,0 +1,489 @@
+/*
+ * jdsp_oracle.c -- CPU restatement of the JeicybooDSP FFT-based spectral path.
+ * TEST INFRASTRUCTURE ONLY (see jdsp_oracle.h for the rules and pinning status).
+ *
+ * Plain C, IEEE double, single thread, structured per frame like the reference
+ * (window and transcendental per-bin path recomputed every frame), so that it
+ * also serves as the "port" CPU baseline timed by bench.py.
+ * Build: make -C oracle   (gcc -O2 -ffp-contract=off: no fused multiply-adds, so
+ * the FFTAlgorithm_ver2 restatement stays bit-identical to the reference build).
+ */
+#include "jdsp_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* FFTAlgorithm_ver2.cpp:15 */
+#define PI_FFTALG 3.14159265358
+/* SpectralSubtraction_final.cpp:52, WienerFilter_final.cpp:41, MFCC...:26 */
+#define PI_APPS 3.141592
+
+/* (short)double as x86-64 gcc/msvc do it: truncate to int32 (cvttsd2si; NaN and
+ * out-of-int32-range give INT_MIN), keep the low 16 bits.  The reference's
+ * out-of-range casts are undefined behaviour in C; this pins them. */
+static short cast_i16(double v)
+{
+    int t;
+    if (!(v > -2147483649.0 && v < 2147483648.0)) t = (int)0x80000000u;
+    else t = (int)v;
+    return (short)(unsigned short)((unsigned)t & 0xFFFFu);
+}
+
+static int ilog2(int n) { int b = 0; while ((1 << b) < n) b++; return b; }
+
+/* ------------------------------------------------------------------------- */
+/* FFTAlgorithm_ver2.cpp:186-207                                              */
+void orc_bitrev_table(int n_fft, int block_len, short *table)
+{
+    /* :188 -- bit count from BLOCK_LEN; (int)log2(512.0) == 9 exactly */
+    int bits = (int)log2((double)block_len);
+    for (int k = 0; k < n_fft; k++) {
+        short walk = (short)k;   /* :192 iTemp */
+        short rev = walk;        /* :193 */
+        for (int i = 1; i < bits; i++) {          /* :195-200, all in 16-bit */
+            walk = (short)(walk >> 1);
+            rev = (short)(rev << 1);
+            rev = (short)(rev | (walk & 1));
+        }
+        table[k] = (short)(rev & (n_fft - 1));    /* :202 */
+    }
+}
+
+/* FFTAlgorithm_ver2.cpp:94-149.  Same butterflies and the same twiddle
+ * expressions; twiddles are evaluated once per (stage, n) instead of once per
+ * element -- cos()/sin() are pure, so the bits are the same. */
+void orc_fft_process(const orc_cplx *in, orc_cplx *out, int n_fft, int forward, int block_len)
+{
+    short *rev = (short *)malloc(sizeof(short) * (size_t)n_fft);
+    orc_cplx *tw = (orc_cplx *)malloc(sizeof(orc_cplx) * (size_t)n_fft);
+    orc_bitrev_table(n_fft, block_len, rev);
+    for (int k = 0; k < n_fft; k++) out[k] = in[rev[k]];        /* :204-205 */
+
+    for (int groups = n_fft / 2;; groups /= 2) {                 /* iNpoint */
+        int span = n_fft / groups;      /* iN2: 2,4,8..  */
+        int half = span / 2;            /* iN1           */
+        int next = span * 2;            /* iN3           */
+        for (int g = 0; g < groups; g++) {                       /* :111-122 */
+            orc_cplx *p = out + (size_t)span * g;
+            for (int m = 0; m < half; m++) {
+                orc_cplx a = p[m], b = p[m + half];
+                p[m].re = a.re + b.re;
+                p[m].im = a.im + b.im;
+                p[m + half].re = a.re - b.re;
+                p[m + half].im = a.im - b.im;
+            }
+        }
+        if (groups == 1) break;                                  /* :124 */
+        for (int n = 0; n < span; n++) {                         /* :135-142 */
+            if (forward) {
+                tw[n].re = cos(-2 * PI_FFTALG * n / (double)next);
+                tw[n].im = sin(-2 * PI_FFTALG * n / (double)next);
+            } else {
+                tw[n].re = cos(2 * PI_FFTALG * n / (double)next);
+                tw[n].im = sin(2 * PI_FFTALG * n / (double)next);
+            }
+        }
+        for (int k = 0; k < groups / 2; k++) {                   /* :128-145 */
+            orc_cplx *p = out + (size_t)k * next + span;
+            for (int n = 0; n < span; n++) {
+                orc_cplx t = p[n];
+                p[n].re = tw[n].re * t.re - tw[n].im * t.im;
+                p[n].im = tw[n].re * t.im + tw[n].im * t.re;
+            }
+        }
+    }
+    free(tw);
+    free(rev);
+}
+
+/* FFTAlgorithm_ver2.cpp:162-173 */
+void orc_dft_process(const short *in, orc_cplx *out, int n_fft)
+{
+    for (int k = 0; k < n_fft; k++)
+        for (int i = 0; i < n_fft; i++) {
+            out[k].re += in[i] * cos(2 * PI_FFTALG * i * k / (double)n_fft);
+            out[k].im += in[i] * -sin(2 * PI_FFTALG * i * k / (double)n_fft);
+        }
+}
+
+/* FFTAlgorithm_ver2.cpp:175-184 */
+void orc_idft_process(const orc_cplx *in, orc_cplx *out, int n_fft)
+{
+    for (int k = 0; k < n_fft; k++)
+        for (int i = 0; i < n_fft; i++) {
+            double c = cos(2 * PI_FFTALG * i * k / (double)n_fft);
+            double s = sin(2 * PI_FFTALG * i * k / (double)n_fft);
+            out[k].re += (in[i].re * c - in[i].im * s);
+            out[k].im += (in[i].re * s + in[i].im * c);
+        }
+}
+
+/* FFTAlgorithm_ver2.cpp:151-160 */
+void orc_ifft_process(const orc_cplx *in, orc_cplx *out, int n_fft)
+{
+    for (int k = 0; k < n_fft; k++)
+        for (int i = 0; i < n_fft; i++) {
+            double c = cos(2 * PI_FFTALG * i * k / (double)n_fft);
+            double s = sin(2 * PI_FFTALG * i * k / (double)n_fft);
+            out[k].re += (in[i].re * c - in[i].im * s) * 1 / (double)n_fft;
+            out[k].im += (in[i].re * s + in[i].im * c) * 1 / (double)n_fft;
+        }
+}
+
+/* FFTAlgorithm_ver2.cpp:62-86 */
+void orc_fft_roundtrip_i16(const short *pcm, int n_blocks, int n_fft, short *out)
+{
+    orc_cplx *a = (orc_cplx *)calloc((size_t)n_fft, sizeof(orc_cplx));
+    orc_cplx *b = (orc_cplx *)calloc((size_t)n_fft, sizeof(orc_cplx));
+    for (int blk = 0; blk < n_blocks; blk++) {
+        const short *src = pcm + (size_t)blk * n_fft;
+        for (int i = 0; i < n_fft; i++) { a[i].re = src[i]; a[i].im = 0.0; }   /* :68-70 */
+        orc_fft_process(a, b, n_fft, 1, n_fft);                                 /* :75 */
+        orc_fft_process(b, a, n_fft, 0, n_fft);                                 /* :77 */
+        for (int i = 0; i < n_fft; i++)
+            out[(size_t)blk * n_fft + i] = cast_i16(a[i].re / (double)n_fft);   /* :80 */
+    }
+    free(a);
+    free(b);
+}
+
+/* ------------------------------------------------------------------------- */
+/* FFTW3 contract: fftw_plan_dft_1d(n, in, out, sign, FFTW_ESTIMATE) +
+ * fftw_execute (SS:229-230,244-245; WF:192-193,215-216; 3D:139-143,154;
+ * MFCC:216-217).  FFTW is not in the reference tree; this is its documented
+ * definition, out[k] = sum_j in[j] exp(sign*2*pi*i*j*k/n), evaluated with an
+ * iterative radix-2 transform whose twiddles come straight from cos/sin of the
+ * true pi.  A small per-size twiddle cache plays the role of the plan. */
+#define ORC_MAX_LOG2 20
+static orc_cplx *g_tw[ORC_MAX_LOG2 + 1];
+static unsigned *g_rev[ORC_MAX_LOG2 + 1];
+
+static void dft_plan(int lg)
+{
+    int n = 1 << lg;
+    if (g_tw[lg]) return;
+    orc_cplx *tw = (orc_cplx *)malloc(sizeof(orc_cplx) * (size_t)(n / 2 + 1));
+    unsigned *rv = (unsigned *)malloc(sizeof(unsigned) * (size_t)n);
+    for (int k = 0; k < n / 2; k++) {
+        double ang = -2.0 * M_PI * (double)k / (double)n;
+        tw[k].re = cos(ang);
+        tw[k].im = sin(ang);
+    }
+    for (int k = 0; k < n; k++) {
+        unsigned r = 0;
+        for (int b = 0; b < lg; b++) r |= ((unsigned)(k >> b) & 1u) << (lg - 1 - b);
+        rv[k] = r;
+    }
+    g_rev[lg] = rv;
+    g_tw[lg] = tw;
+}
+
+void orc_dft_c2c(const orc_cplx *in, orc_cplx *out, int n, int sign)
+{
+    int lg = ilog2(n);
+    dft_plan(lg);
+    const orc_cplx *tw = g_tw[lg];
+    const unsigned *rv = g_rev[lg];
+    for (int k = 0; k < n; k++) out[k] = in[rv[k]];
+    for (int len = 2; len <= n; len <<= 1) {
+        int half = len >> 1, step = n / len;
+        for (int base = 0; base < n; base += len)
+            for (int j = 0; j < half; j++) {
+                double wr = tw[j * step].re;
+                double wi = sign < 0 ? tw[j * step].im : -tw[j * step].im;
+                orc_cplx u = out[base + j], v = out[base + j + half];
+                double tr = v.re * wr - v.im * wi;
+                double ti = v.re * wi + v.im * wr;
+                out[base + j].re = u.re + tr;
+                out[base + j].im = u.im + ti;
+                out[base + j + half].re = u.re - tr;
+                out[base + j + half].im = u.im - ti;
+            }
+    }
+}
+
+/* ------------------------------------------------------------------------- */
+/* SS:226 / WF:189 / MFCC:213 */
+void orc_hamming(int n, double *w)
+{
+    for (int i = 0; i < n; i++) w[i] = (0.54 - 0.46 * cos(2 * PI_APPS * i / (n - 1)));
+}
+
+/* SS:218-230 (== WF:181-193): [previous hop, current hop] -> *window -> forward */
+static void windowed_forward(const short *frame, int n, orc_cplx *buf, orc_cplx *spec)
+{
+    for (int i = 0; i < n; i++) { buf[i].re = frame[i]; buf[i].im = 0.0; }
+    for (int i = 0; i < n; i++)                                   /* window recomputed per frame, as the reference does */
+        buf[i].re *= (0.54 - 0.46 * cos(2 * PI_APPS * i / (n - 1)));
+    orc_dft_c2c(buf, spec, n, -1);
+}
+
+void orc_stft(const short *pcm, long n_frames, int n, int hop, orc_cplx *spec)
+{
+    orc_cplx *buf = (orc_cplx *)malloc(sizeof(orc_cplx) * (size_t)n);
+    for (long f = 0; f < n_frames; f++)
+        windowed_forward(pcm + (size_t)f * hop, n, buf, spec + (size_t)f * n);
+    free(buf);
+}
+
+/* SS:121-156 == WF:261-296 */
+int orc_vad_block(const short *block, int block_len, double *energy, int *zcr)
+{
+    const int n = 2 * block_len;                 /* FFT_PROCESSING_SIZE = KEEP_LEN + BLOCK_LEN */
+    short *s = (short *)calloc((size_t)n + 1, sizeof(short));   /* s[n] = 0: defined value for the :139 over-read */
+    double e = 0.0;
+    int z = 0;
+    memcpy(s + block_len, block, sizeof(short) * (size_t)block_len);   /* keep half stays zero (:127, :154 dead) */
+    for (int i = 0; i < n; i++) {
+        s[i] = (short)(s[i] * (0.54 - 0.46 * cos(2 * PI_APPS * i / (n - 1))));   /* :131 truncates back to short */
+        e += pow(s[i], 2.0);                                                    /* :135 */
+        if (s[i] * s[i + 1] < 0) z++;            /* :139: s[i+1] is not windowed yet */
+    }
+    e /= n;                                      /* :143 */
+    if (energy) *energy = e;
+    if (zcr) *zcr = z;
+    free(s);
+    return (e > 700.0 || z < 200.0) ? 1 : 0;     /* :147 */
+}
+
+/* ------------------------------------------------------------------------- */
+#define DN_BLOCK 512
+#define DN_FFT 1024
+struct orc_denoise {
+    int mode;
+    /* main(): SS:68-72 */
+    int run_len;                 /* iNumOfIteration */
+    short stash[DN_BLOCK];       /* rgsTempBuffer */
+    double noise[DN_FFT];        /* rgdEstimatedNS */
+    /* EstimateNoiseSpectrum statics: SS:161,164 */
+    double avg[DN_FFT];
+    short est_keep[DN_BLOCK];
+    /* SpectralSubtraction / WienerFiltering statics: SS:202,208-209 */
+    int calls;
+    short keep[DN_BLOCK];
+    double ola[DN_FFT];
+    int last_voice;
+    orc_cplx a[DN_FFT], b[DN_FFT];
+};
+
+orc_denoise *orc_denoise_create(int mode)
+{
+    orc_denoise *s = (orc_denoise *)calloc(1, sizeof(orc_denoise));
+    s->mode = mode;
+    return s;
+}
+void orc_denoise_destroy(orc_denoise *s) { free(s); }
+const double *orc_denoise_noise(const orc_denoise *s) { return s->noise; }
+int orc_denoise_last_voice(const orc_denoise *s) { return s->last_voice; }
+
+/* SS:159-198 == WF:120-159 */
+static void estimate_noise(orc_denoise *s, const short *in)
+{
+    short frame[DN_FFT];
+    if (s->run_len == 2) memcpy(s->est_keep, s->stash, sizeof(s->est_keep));   /* :165-167 */
+    memcpy(frame, s->est_keep, sizeof(s->est_keep));
+    memcpy(frame + DN_BLOCK, in, sizeof(short) * DN_BLOCK);
+    windowed_forward(frame, DN_FFT, s->a, s->b);                               /* :168-180 */
+    for (int i = 0; i < DN_FFT; i++) {                                         /* :182-187 */
+        s->avg[i] += sqrt(s->b[i].re * s->b[i].re + s->b[i].im * s->b[i].im);
+        if (s->run_len >= 3) s->avg[i] /= 2.0;
+    }
+    if (s->run_len == 10)                                                      /* :189-193 */
+        memcpy(s->noise, s->avg, sizeof(s->noise));
+    memcpy(s->est_keep, in, sizeof(s->est_keep));                              /* :195 */
+}
+
+int orc_denoise_block(orc_denoise *s, const short *in, short *out, double *ola_out)
+{
+    short frame[DN_FFT];
+    /* main loop, SS:98-109 */
+    s->last_voice = orc_vad_block(in, DN_BLOCK, NULL, NULL);
+    if (!s->last_voice) {
+        s->run_len++;
+        if (s->run_len == 1) memcpy(s->stash, in, sizeof(s->stash));
+        else estimate_noise(s, in);
+    } else {
+        s->run_len = 0;
+    }
+    /* SS:201-264 / WF:162-235 */
+    s->calls++;
+    if (s->calls == 1) {                                        /* :211-216 */
+        memcpy(s->keep, in, sizeof(s->keep));
+        return 0;
+    }
+    memcpy(frame, s->keep, sizeof(s->keep));
+    memcpy(frame + DN_BLOCK, in, sizeof(short) * DN_BLOCK);
+    windowed_forward(frame, DN_FFT, s->a, s->b);                /* :218-230 */
+    for (int i = 0; i < DN_FFT; i++) {
+        double re = s->b[i].re, im = s->b[i].im;
+        double ang = atan2(im, re);                             /* SS:234 / WF:197 */
+        double amp;
+        if (s->mode == ORC_SPECSUB) {
+            amp = sqrt(re * re + im * im) - s->noise[i];        /* SS:238, no clamp */
+        } else {
+            double p = re * re + im * im;                       /* WF:201 */
+            double r = (pow(s->noise[i], 2.0) / p);             /* WF:204 (0/0 -> NaN stays NaN) */
+            if (r >= 1.0) r = 1.0;                              /* WF:205-207 */
+            amp = fabs(sqrt(p)) * (1.0 - r);                    /* WF:208 */
+        }
+        s->a[i].re = amp * cos(ang);                            /* SS:240-241 / WF:211-212 */
+        s->a[i].im = amp * sin(ang);
+    }
+    orc_dft_c2c(s->a, s->b, DN_FFT, +1);                        /* SS:244-245 */
+    for (int i = 0; i < DN_FFT; i++) s->ola[i] += 1. / DN_FFT * s->b[i].re;   /* SS:248 */
+    for (int i = 0; i < DN_BLOCK; i++) {
+        out[i] = cast_i16(s->ola[i]);                           /* SS:252 */
+        if (ola_out) ola_out[i] = s->ola[i];
+    }
+    memmove(s->ola, s->ola + DN_BLOCK, sizeof(double) * DN_BLOCK);   /* SS:255-256 */
+    memset(s->ola + DN_BLOCK, 0, sizeof(double) * DN_BLOCK);
+    memcpy(s->keep, in, sizeof(s->keep));                       /* SS:257 */
+    return s->calls >= 3;                                       /* SS:260-263 */
+}
+
+long orc_denoise_stream(int mode, const short *pcm, long n_blocks, short *out, double *ola_out)
+{
+    orc_denoise *s = orc_denoise_create(mode);
+    short blk[DN_BLOCK];
+    double pre[DN_BLOCK];
+    long n_out = 0;
+    for (long b = 0; b < n_blocks; b++) {
+        if (orc_denoise_block(s, pcm + (size_t)b * DN_BLOCK, blk, pre)) {
+            memcpy(out + (size_t)n_out * DN_BLOCK, blk, sizeof(blk));
+            if (ola_out) memcpy(ola_out + (size_t)n_out * DN_BLOCK, pre, sizeof(pre));
+            n_out++;
+        }
+    }
+    orc_denoise_destroy(s);
+    return n_out;
+}
+
+/* ------------------------------------------------------------------------- */
+/* Fast_Convolution_Based_3DAudio_Impl.cpp:82-84,102-177 */
+long orc_fastconv_stream(const short *pcm, long n_blocks, const double *taps, int n_taps,
+                         int n_fft, short *out, double *pre_cast)
+{
+    const int block = n_fft - n_taps + 1;                    /* 1024 native */
+    const int save = n_taps - 1;                             /* SAVE_LENGTH 7168 */
+    const int n_hist = (save + block - 1) / block;           /* MAX_QUEUE_SIZE 7 */
+    orc_cplx *x = (orc_cplx *)calloc((size_t)n_fft, sizeof(orc_cplx));
+    orc_cplx *X = (orc_cplx *)calloc((size_t)n_fft, sizeof(orc_cplx));
+    orc_cplx *h = (orc_cplx *)calloc((size_t)n_fft, sizeof(orc_cplx));
+    orc_cplx *H = (orc_cplx *)calloc((size_t)n_fft, sizeof(orc_cplx));
+    long n_out = 0;
+    for (int i = 0; i < n_taps; i++) h[i].re = taps[i];      /* :82-84 */
+    for (long b = n_hist; b < n_blocks; b++) {               /* calls 1..n_hist return false (:119-123) */
+        long end = (b + 1) * (long)block;                    /* one past the newest sample */
+        for (int i = 0; i < n_fft; i++) {                    /* :125-137 */
+            long pos = end - n_fft + i;
+            /* blocks queued by the first n_hist calls are uninitialised heap (:120): zero here */
+            x[i].re = (pos >= (long)n_hist * block) ? (double)pcm[pos] : 0.0;
+            x[i].im = 0.0;
+        }
+        orc_dft_c2c(x, X, n_fft, -1);                        /* :142 */
+        orc_dft_c2c(h, H, n_fft, -1);                        /* :143 -- recomputed every block, as the reference */
+        for (int i = 0; i < n_fft; i++) {                    /* :149-152 */
+            double re = X[i].re * H[i].re - X[i].im * H[i].im;
+            double im = X[i].re * H[i].im + X[i].im * H[i].re;
+            x[i].re = re;
+            x[i].im = im;
+        }
+        orc_dft_c2c(x, X, n_fft, +1);                        /* :154 */
+        for (int i = 0; i < block; i++) {                    /* :156-158 */
+            double v = X[i + n_taps - 1].re * 1. / n_fft;
+            out[(size_t)n_out * block + i] = cast_i16(v);
+            if (pre_cast) pre_cast[(size_t)n_out * block + i] = v;
+        }
+        n_out++;
+    }
+    free(x); free(X); free(h); free(H);
+    return n_out;
+}
+
+/* ------------------------------------------------------------------------- */
+/* MFCCFeatureExtraction_auto_version1.cpp:23-33 */
+void orc_mfcc_native_cfg(orc_mfcc_cfg *c)
+{
+    c->win_len = 1024; c->hop = 512; c->n_fft = 1024; c->n_bins = 512;
+    c->n_chan = 38; c->n_cep = 12; c->lifter = 22;
+    c->half_rate = 22050.0; c->preemph = 0.96;
+}
+
+/* :118-152 */
+void orc_mel_init(const orc_mfcc_cfg *c, double *mel, int *fi, double *fb)
+{
+    const int C = c->n_chan, NB = c->n_bins;
+    double unit = 1127.0 * log(1 + (c->half_rate / 700.0)) / (C + 1);      /* :124 */
+    for (int i = 1; i <= C + 1; i++) {                                     /* :126-129 */
+        double m = unit * i;
+        mel[i - 1] = 700 * (exp(m / 1127.0) - 1.0);
+    }
+    for (int i = 0, k = 0; i < NB; i++) {                                  /* :131-137 */
+        if ((i / (double)(NB - 1)) * c->half_rate > mel[k]) {
+            if (k < C) k++;
+        }
+        fi[i] = k;
+    }
+    for (int i = 0; i < NB; i++) {                                         /* :139-150 */
+        int k = fi[i];
+        double f = (i / (double)(NB - 1)) * c->half_rate;
+        if (k == 0) fb[i] = (mel[k] - f) / (mel[k] - 0);
+        else fb[i] = (mel[k] - f) / (mel[k] - mel[k - 1]);
+        if (fb[i] < 0) fb[i] = 0;
+    }
+}
+
+void orc_mfcc_frame(const orc_mfcc_cfg *c, const int *fi, const double *fb,
+                    const short *frame, double *cep)
+{
+    const int W = c->win_len, N = c->n_fft, C = c->n_chan;
+    orc_cplx *x = (orc_cplx *)calloc((size_t)N, sizeof(orc_cplx));
+    orc_cplx *X = (orc_cplx *)calloc((size_t)N, sizeof(orc_cplx));
+    double *mag = (double *)calloc((size_t)N, sizeof(double));
+    double *m = (double *)calloc((size_t)C, sizeof(double));
+    for (int i = 1; i < W; i++)                                            /* :208-210, x[0] stays 0 */
+        x[i].re = frame[i] - c->preemph * frame[i - 1];
+    for (int i = 0; i < W; i++)                                            /* :212-214 */
+        x[i].re *= (0.54 - 0.46 * cos(2 * PI_APPS * i / (W - 1)));
+    orc_dft_c2c(x, X, N, -1);                                              /* :216-217 */
+    for (int i = 0; i < N; i++)                                            /* :218-220 */
+        mag[i] = sqrt(pow(X[i].re, 2) + pow(X[i].im, 2));
+    for (int i = 0; i < c->n_bins; i++) {                                  /* :157-168 */
+        int k = fi[i];
+        if (k == 0) {
+            m[k] += (1 - fb[i]) * mag[i];
+        } else {
+            m[k - 1] += fb[i] * mag[i];
+            if (k != C) m[k] += (1 - fb[i]) * mag[i];
+        }
+    }
+    for (int i = 0; i < C; i++) m[i] = log(m[i]);                          /* :170-172 */
+    for (int i = 1; i <= c->n_cep; i++) {                                  /* :178-182 */
+        double acc = 0.0;
+        for (int k = 1; k <= C; k++)
+            acc += sqrt(2.0 / C) * m[k - 1] * cos(PI_APPS * i * (k - 0.5) / (double)C);
+        cep[i - 1] = acc * (1 + 0.5 * c->lifter * sin(PI_APPS * i / c->lifter));   /* :189 */
+    }
+    free(x); free(X); free(mag); free(m);
+}
+
+/* :86-104 + :203-205,228 */
+long orc_mfcc_stream(const orc_mfcc_cfg *c, const short *pcm, long n_blocks, double *feats)
+{
+    const int hop = c->hop, W = c->win_len;
+    if (W != 2 * hop) return -1;
+    int *fi = (int *)calloc((size_t)c->n_bins, sizeof(int));
+    double *fb = (double *)calloc((size_t)c->n_bins, sizeof(double));
+    double *mel = (double *)calloc((size_t)c->n_chan + 1, sizeof(double));
+    short *padded = (short *)calloc((size_t)hop + (size_t)n_blocks * W, sizeof(short));
+    long n_out = 0;
+    orc_mel_init(c, mel, fi, fb);                                          /* :85 */
+    memcpy(padded + hop, pcm, sizeof(short) * (size_t)n_blocks * W);       /* keep buffer starts at zero (:198) */
+    for (long f = 1; f < 2 * n_blocks; f++) {                              /* very first vector skipped (:95-97) */
+        orc_mfcc_frame(c, fi, fb, padded + (size_t)f * hop, feats + (size_t)n_out * c->n_cep);
+        n_out++;
+    }
+    free(fi); free(fb); free(mel); free(padded);
+    return n_out;
+}

@@ -1,0 +1,111 @@
+/*
+ * jdsp_oracle.h -- CPU restatement of the JeicybooDSP FFT-based spectral path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product:
+ * only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library, and there only as the checker / the timed CPU baseline.
+ * The product path (jeicyboodsp_amd/libjdsp.so) never links or calls it.
+ *
+ * Every function cites the reference file:line it restates (paths relative to
+ * the reference checkout).  Arithmetic is IEEE double like the reference.
+ *
+ * Pinning status (see DESIGN.md "Oracle"):
+ *   - orc_bitrev_table / orc_fft_process / orc_dft_process / orc_idft_process /
+ *     orc_ifft_process / orc_fft_roundtrip_i16 are pinned BIT-EXACTLY against
+ *     FFTAlgorithm_ver2.cpp compiled from where it lies (oracle/_ref, recipe in
+ *     oracle/Makefile) and against the committed fixtures tests/golden/fftalg_*.
+ *   - the four application chains (spectral subtraction, Wiener, fast
+ *     convolution, MFCC) call FFTW3, which is absent from the reference tree and
+ *     from this image, so the reference programs are unbuildable here and those
+ *     chains are "parity unpinned" at the FFTW boundary: the transform is taken
+ *     as FFTW's documented contract (unnormalised c2c DFT, sign -1 forward),
+ *     orc_dft_c2c, itself cross-checked against the pinned orc_fft_process.
+ */
+#ifndef JDSP_ORACLE_H
+#define JDSP_ORACLE_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* FFTAlgorithm_ver2.cpp:20-22 (COMPLEX) / fftw_complex = double[2] */
+typedef struct { double re, im; } orc_cplx;
+
+/* ---- FFTAlgorithm_ver2.cpp ------------------------------------------------ */
+/* :186-207 Bitrev: table only.  bits come from block_len (the reference takes
+ * them from BLOCK_LEN, not from the transform length: :188). */
+void orc_bitrev_table(int n_fft, int block_len, short *table);
+/* :94-149 FFTProcess (forward != 0: sign -1).  block_len as above (512 native). */
+void orc_fft_process(const orc_cplx *in, orc_cplx *out, int n_fft, int forward, int block_len);
+/* :162-173 DFTProcess (accumulates into out) */
+void orc_dft_process(const short *in, orc_cplx *out, int n_fft);
+/* :175-184 IDFTProcess (unnormalised, accumulates) */
+void orc_idft_process(const orc_cplx *in, orc_cplx *out, int n_fft);
+/* :151-160 IFFTProcess (1/N-normalised O(N^2) IDFT, accumulates) */
+void orc_ifft_process(const orc_cplx *in, orc_cplx *out, int n_fft);
+/* :62-86 main loop body: int16 -> FFT -> IFFT -> (short)(re/N), n_blocks blocks of n_fft */
+void orc_fft_roundtrip_i16(const short *pcm, int n_blocks, int n_fft, short *out);
+
+/* ---- FFTW contract (third-party, absent): unnormalised c2c DFT ------------- */
+/* sign = -1 forward, +1 backward.  n must be a power of two. */
+void orc_dft_c2c(const orc_cplx *in, orc_cplx *out, int n, int sign);
+
+/* ---- shared pieces of the application programs ---------------------------- */
+/* SpectralSubtraction_final.cpp:226 etc.: 0.54-0.46cos(2*PI*i/(n-1)), PI=3.141592 */
+void orc_hamming(int n, double *w);
+/* SS:218-230 / WF:181-193 framing + window + forward transform for a whole
+ * stream: frame f = samples [hop*f, hop*f+n), n_frames frames, full spectrum. */
+void orc_stft(const short *pcm, long n_frames, int n, int hop, orc_cplx *spec);
+/* SS:121-156 == WF:261-296 VoiceActivityDetection on one block (keep buffer is
+ * always zero: the update at :154 is unreachable).  The out-of-bounds read of
+ * frame[n] at i == n-1 (:139) is defined here as 0.  Returns 1 = voice.
+ * energy/zcr may be NULL. */
+int orc_vad_block(const short *block, int block_len, double *energy, int *zcr);
+
+/* SS:62-119,159-264 / WF:52-235: the whole per-block state machine. */
+typedef struct orc_denoise orc_denoise;
+enum { ORC_SPECSUB = 0, ORC_WIENER = 1 };
+orc_denoise *orc_denoise_create(int mode);
+void orc_denoise_destroy(orc_denoise *s);
+/* One iteration of main's while-loop for one 512-sample block.  Returns 1 when
+ * the reference would fwrite() out_block.  ola_out (may be NULL) receives the
+ * 512 pre-cast doubles behind out_block. */
+int orc_denoise_block(orc_denoise *s, const short *in_block, short *out_block, double *ola_out);
+/* Current noise estimate (1024 doubles) and the flag/run length of the last block. */
+const double *orc_denoise_noise(const orc_denoise *s);
+int orc_denoise_last_voice(const orc_denoise *s);
+/* Whole stream: n_blocks blocks in, returns blocks written (n_blocks-2). */
+long orc_denoise_stream(int mode, const short *pcm, long n_blocks, short *out, double *ola_out);
+
+/* Fast_Convolution_Based_3DAudio_Impl.cpp:102-177 overlap-save convolver,
+ * generalised: n_fft transform, n_taps filter, block = n_fft - n_taps + 1
+ * (native 8192 / 7169 / 1024).  The reference's first (n_fft/block - 1)
+ * queued blocks are uninitialised heap (:120); they are defined as ZERO here,
+ * which makes emitted block e the convolution of the stream starting at block
+ * (n_hist) with zero history.  Returns blocks written (n_blocks - n_hist). */
+long orc_fastconv_stream(const short *pcm, long n_blocks, const double *taps, int n_taps,
+                         int n_fft, short *out, double *pre_cast);
+
+/* MFCCFeatureExtraction_auto_version1.cpp:118-231, parametrised.  Native:
+ * win 1024, hop 512, n_fft 1024, n_bins 512, 38 channels, half_rate 22050,
+ * 12 cepstra, lifter 22, pre-emphasis 0.96. */
+typedef struct {
+    int win_len, hop, n_fft, n_bins, n_chan, n_cep, lifter;
+    double half_rate, preemph;
+} orc_mfcc_cfg;
+void orc_mfcc_native_cfg(orc_mfcc_cfg *c);
+/* :118-152 MelFilterBankInit: mel_freqs[n_chan+1], fi_bins[n_bins], fbank[n_bins] */
+void orc_mel_init(const orc_mfcc_cfg *c, double *mel_freqs, int *fi_bins, double *fbank);
+/* :194-231 per frame: frame = win_len int16 samples -> n_cep doubles.
+ * x[0] stays 0 (:208 starts at i=1). */
+void orc_mfcc_frame(const orc_mfcc_cfg *c, const int *fi_bins, const double *fbank,
+                    const short *frame, double *cep);
+/* :86-104 one file as the first of a run: n_blocks blocks of 2*hop samples
+ * (keep starts at zero, very first vector skipped) -> 2*n_blocks-1 vectors.
+ * Only valid for win_len == 2*hop.  Returns vectors written. */
+long orc_mfcc_stream(const orc_mfcc_cfg *c, const short *pcm, long n_blocks, double *feats);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

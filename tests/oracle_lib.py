@@ -1,0 +1,275 @@
+"""ctypes bindings for the CPU oracle (oracle/libjdsp_oracle.so) and, when it
+has been built in the authoring container, the compiled reference translation
+unit oracle/_ref/libref_fftalg_*.so.
+
+Test infrastructure only: imported by tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg, never by the product package.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+
+_c_short_p = C.POINTER(C.c_short)
+_c_double_p = C.POINTER(C.c_double)
+_c_int_p = C.POINTER(C.c_int)
+
+
+class MfccCfg(C.Structure):
+    _fields_ = [("win_len", C.c_int), ("hop", C.c_int), ("n_fft", C.c_int), ("n_bins", C.c_int),
+                ("n_chan", C.c_int), ("n_cep", C.c_int), ("lifter", C.c_int),
+                ("half_rate", C.c_double), ("preemph", C.c_double)]
+
+
+def _p(a, t):
+    return a.ctypes.data_as(t)
+
+
+def build_oracle():
+    subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, "libjdsp_oracle.so"])
+
+
+class Oracle:
+    SPECSUB, WIENER = 0, 1
+
+    def __init__(self, path):
+        L = self.lib = C.CDLL(path)
+        L.orc_bitrev_table.argtypes = [C.c_int, C.c_int, _c_short_p]
+        L.orc_fft_process.argtypes = [_c_double_p, _c_double_p, C.c_int, C.c_int, C.c_int]
+        L.orc_dft_process.argtypes = [_c_short_p, _c_double_p, C.c_int]
+        L.orc_idft_process.argtypes = [_c_double_p, _c_double_p, C.c_int]
+        L.orc_ifft_process.argtypes = [_c_double_p, _c_double_p, C.c_int]
+        L.orc_fft_roundtrip_i16.argtypes = [_c_short_p, C.c_int, C.c_int, _c_short_p]
+        L.orc_dft_c2c.argtypes = [_c_double_p, _c_double_p, C.c_int, C.c_int]
+        L.orc_hamming.argtypes = [C.c_int, _c_double_p]
+        L.orc_stft.argtypes = [_c_short_p, C.c_long, C.c_int, C.c_int, _c_double_p]
+        L.orc_vad_block.argtypes = [_c_short_p, C.c_int, _c_double_p, _c_int_p]
+        L.orc_vad_block.restype = C.c_int
+        L.orc_denoise_stream.argtypes = [C.c_int, _c_short_p, C.c_long, _c_short_p, _c_double_p]
+        L.orc_denoise_stream.restype = C.c_long
+        L.orc_denoise_create.argtypes = [C.c_int]
+        L.orc_denoise_create.restype = C.c_void_p
+        L.orc_denoise_destroy.argtypes = [C.c_void_p]
+        L.orc_denoise_block.argtypes = [C.c_void_p, _c_short_p, _c_short_p, _c_double_p]
+        L.orc_denoise_block.restype = C.c_int
+        L.orc_denoise_noise.argtypes = [C.c_void_p]
+        L.orc_denoise_noise.restype = _c_double_p
+        L.orc_denoise_last_voice.argtypes = [C.c_void_p]
+        L.orc_denoise_last_voice.restype = C.c_int
+        L.orc_fastconv_stream.argtypes = [_c_short_p, C.c_long, _c_double_p, C.c_int, C.c_int,
+                                          _c_short_p, _c_double_p]
+        L.orc_fastconv_stream.restype = C.c_long
+        L.orc_mfcc_native_cfg.argtypes = [C.POINTER(MfccCfg)]
+        L.orc_mel_init.argtypes = [C.POINTER(MfccCfg), _c_double_p, _c_int_p, _c_double_p]
+        L.orc_mfcc_frame.argtypes = [C.POINTER(MfccCfg), _c_int_p, _c_double_p, _c_short_p, _c_double_p]
+        L.orc_mfcc_stream.argtypes = [C.POINTER(MfccCfg), _c_short_p, C.c_long, _c_double_p]
+        L.orc_mfcc_stream.restype = C.c_long
+
+    # --- FFTAlgorithm_ver2 --------------------------------------------------
+    def bitrev_table(self, n_fft, block_len=None):
+        t = np.zeros(n_fft, np.int16)
+        self.lib.orc_bitrev_table(n_fft, block_len or n_fft, _p(t, _c_short_p))
+        return t
+
+    def fft_process(self, x, forward=True, block_len=None):
+        x = np.ascontiguousarray(x, np.complex128)
+        out = np.zeros_like(x)
+        n = x.shape[-1]
+        for xi, oi in zip(x.reshape(-1, n), out.reshape(-1, n)):
+            self.lib.orc_fft_process(_p(xi, _c_double_p), _p(oi, _c_double_p), n, int(forward), block_len or n)
+        return out
+
+    def dft_process(self, s):
+        s = np.ascontiguousarray(s, np.int16)
+        out = np.zeros(s.shape[-1], np.complex128)
+        self.lib.orc_dft_process(_p(s, _c_short_p), _p(out, _c_double_p), s.shape[-1])
+        return out
+
+    def idft_process(self, x):
+        x = np.ascontiguousarray(x, np.complex128)
+        out = np.zeros_like(x)
+        self.lib.orc_idft_process(_p(x, _c_double_p), _p(out, _c_double_p), x.shape[-1])
+        return out
+
+    def ifft_process(self, x):
+        x = np.ascontiguousarray(x, np.complex128)
+        out = np.zeros_like(x)
+        self.lib.orc_ifft_process(_p(x, _c_double_p), _p(out, _c_double_p), x.shape[-1])
+        return out
+
+    def fft_roundtrip_i16(self, pcm, n_fft):
+        pcm = np.ascontiguousarray(pcm, np.int16)
+        nb = pcm.size // n_fft
+        out = np.zeros(nb * n_fft, np.int16)
+        self.lib.orc_fft_roundtrip_i16(_p(pcm, _c_short_p), nb, n_fft, _p(out, _c_short_p))
+        return out
+
+    def dft_c2c(self, x, sign=-1):
+        x = np.ascontiguousarray(x, np.complex128)
+        out = np.zeros_like(x)
+        n = x.shape[-1]
+        for xi, oi in zip(x.reshape(-1, n), out.reshape(-1, n)):
+            self.lib.orc_dft_c2c(_p(xi, _c_double_p), _p(oi, _c_double_p), n, sign)
+        return out
+
+    # --- applications -------------------------------------------------------
+    def hamming(self, n):
+        w = np.zeros(n, np.float64)
+        self.lib.orc_hamming(n, _p(w, _c_double_p))
+        return w
+
+    def stft(self, pcm, n_frames, n=1024, hop=512):
+        pcm = np.ascontiguousarray(pcm, np.int16)
+        assert pcm.size >= (n_frames - 1) * hop + n
+        out = np.zeros((n_frames, n), np.complex128)
+        self.lib.orc_stft(_p(pcm, _c_short_p), n_frames, n, hop, _p(out, _c_double_p))
+        return out
+
+    def vad_block(self, block):
+        block = np.ascontiguousarray(block, np.int16)
+        e = C.c_double()
+        z = C.c_int()
+        v = self.lib.orc_vad_block(_p(block, _c_short_p), block.size, C.byref(e), C.byref(z))
+        return bool(v), e.value, z.value
+
+    def denoise_stream(self, mode, pcm):
+        pcm = np.ascontiguousarray(pcm, np.int16)
+        nb = pcm.size // 512
+        out = np.zeros(max(nb, 1) * 512, np.int16)
+        pre = np.zeros(max(nb, 1) * 512, np.float64)
+        n = self.lib.orc_denoise_stream(mode, _p(pcm, _c_short_p), nb, _p(out, _c_short_p), _p(pre, _c_double_p))
+        return out[:n * 512].copy(), pre[:n * 512].copy()
+
+    def denoise_trace(self, mode, pcm):
+        """Block-by-block run that also returns the VAD flags and every latched noise estimate."""
+        pcm = np.ascontiguousarray(pcm, np.int16)
+        nb = pcm.size // 512
+        h = self.lib.orc_denoise_create(mode)
+        out, pre, flags, noises, ver = [], [], [], [np.zeros(1024)], []
+        ob = np.zeros(512, np.int16)
+        pb = np.zeros(512, np.float64)
+        for b in range(nb):
+            blk = pcm[b * 512:(b + 1) * 512]
+            ok = self.lib.orc_denoise_block(h, _p(blk, _c_short_p), _p(ob, _c_short_p), _p(pb, _c_double_p))
+            cur = np.ctypeslib.as_array(self.lib.orc_denoise_noise(h), shape=(1024,)).copy()
+            if not np.array_equal(cur, noises[-1]):
+                noises.append(cur)
+            ver.append(len(noises) - 1)
+            flags.append(self.lib.orc_denoise_last_voice(h))
+            if ok:
+                out.append(ob.copy())
+                pre.append(pb.copy())
+        self.lib.orc_denoise_destroy(h)
+        cat = lambda l, dt: np.concatenate(l) if l else np.zeros(0, dt)
+        return cat(out, np.int16), cat(pre, np.float64), np.array(flags, np.int32), np.stack(noises), np.array(ver, np.int32)
+
+    def fastconv_stream(self, pcm, taps, n_fft):
+        pcm = np.ascontiguousarray(pcm, np.int16)
+        taps = np.ascontiguousarray(taps, np.float64)
+        block = n_fft - taps.size + 1
+        nb = pcm.size // block
+        out = np.zeros(max(nb, 1) * block, np.int16)
+        pre = np.zeros(max(nb, 1) * block, np.float64)
+        n = self.lib.orc_fastconv_stream(_p(pcm, _c_short_p), nb, _p(taps, _c_double_p), taps.size, n_fft,
+                                         _p(out, _c_short_p), _p(pre, _c_double_p))
+        return out[:n * block].copy(), pre[:n * block].copy()
+
+    def mfcc_native_cfg(self):
+        c = MfccCfg()
+        self.lib.orc_mfcc_native_cfg(C.byref(c))
+        return c
+
+    def mfcc_cfg(self, **kw):
+        c = self.mfcc_native_cfg()
+        for k, v in kw.items():
+            setattr(c, k, v)
+        return c
+
+    def mel_init(self, cfg):
+        mel = np.zeros(cfg.n_chan + 1, np.float64)
+        fi = np.zeros(cfg.n_bins, np.int32)
+        fb = np.zeros(cfg.n_bins, np.float64)
+        self.lib.orc_mel_init(C.byref(cfg), _p(mel, _c_double_p), _p(fi, _c_int_p), _p(fb, _c_double_p))
+        return mel, fi, fb
+
+    def mfcc_frames(self, cfg, pcm, n_frames, first_frame=0):
+        """frame j = pcm[hop*(first_frame+j) : +win_len]"""
+        pcm = np.ascontiguousarray(pcm, np.int16)
+        _, fi, fb = self.mel_init(cfg)
+        out = np.zeros((n_frames, cfg.n_cep), np.float64)
+        for j in range(n_frames):
+            fr = np.ascontiguousarray(pcm[cfg.hop * (first_frame + j):cfg.hop * (first_frame + j) + cfg.win_len])
+            assert fr.size == cfg.win_len
+            self.lib.orc_mfcc_frame(C.byref(cfg), _p(fi, _c_int_p), _p(fb, _c_double_p), _p(fr, _c_short_p),
+                                    _p(out[j], _c_double_p))
+        return out
+
+    def mfcc_stream(self, cfg, pcm):
+        pcm = np.ascontiguousarray(pcm, np.int16)
+        nb = pcm.size // cfg.win_len
+        out = np.zeros((max(2 * nb - 1, 1), cfg.n_cep), np.float64)
+        n = self.lib.orc_mfcc_stream(C.byref(cfg), _p(pcm, _c_short_p), nb, _p(out, _c_double_p))
+        return out[:max(n, 0)].copy()
+
+
+def load_oracle():
+    path = os.path.join(ORACLE_DIR, "libjdsp_oracle.so")
+    if not os.path.exists(path):
+        build_oracle()
+    return Oracle(path)
+
+
+class RefFftAlg:
+    """FFTAlgorithm_ver2.cpp compiled from the reference checkout (oracle/_ref)."""
+
+    def __init__(self, path):
+        L = self.lib = C.CDLL(path)
+        L.ref_Bitrev_table.argtypes = [C.c_int, _c_short_p]
+        L.ref_FFTProcess.argtypes = [_c_double_p, _c_double_p, C.c_int, C.c_int]
+        L.ref_DFTProcess.argtypes = [_c_short_p, _c_double_p, C.c_int]
+        L.ref_IDFTProcess.argtypes = [_c_double_p, _c_double_p, C.c_int]
+        L.ref_IFFTProcess.argtypes = [_c_double_p, _c_double_p, C.c_int]
+        L.ref_block_len.restype = C.c_int
+        self.block_len = L.ref_block_len()
+
+    def bitrev_table(self, n_fft):
+        t = np.zeros(n_fft, np.int16)
+        self.lib.ref_Bitrev_table(n_fft, _p(t, _c_short_p))
+        return t
+
+    def fft_process(self, x, forward=True):
+        x = np.ascontiguousarray(x, np.complex128)
+        out = np.zeros_like(x)
+        self.lib.ref_FFTProcess(_p(x, _c_double_p), _p(out, _c_double_p), x.size, int(forward))
+        return out
+
+    def dft_process(self, s):
+        s = np.ascontiguousarray(s, np.int16)
+        out = np.zeros(s.size, np.complex128)
+        self.lib.ref_DFTProcess(_p(s, _c_short_p), _p(out, _c_double_p), s.size)
+        return out
+
+    def idft_process(self, x):
+        x = np.ascontiguousarray(x, np.complex128)
+        out = np.zeros_like(x)
+        self.lib.ref_IDFTProcess(_p(x, _c_double_p), _p(out, _c_double_p), x.size)
+        return out
+
+    def ifft_process(self, x):
+        x = np.ascontiguousarray(x, np.complex128)
+        out = np.zeros_like(x)
+        self.lib.ref_IFFTProcess(_p(x, _c_double_p), _p(out, _c_double_p), x.size)
+        return out
+
+
+def ref_path(block_len=512):
+    return os.path.join(ORACLE_DIR, "_ref", "libref_fftalg_%d.so" % block_len)
+
+
+def load_ref(block_len=512):
+    p = ref_path(block_len)
+    return RefFftAlg(p) if os.path.exists(p) else None
