@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark: STFT frames/s (1024-pt, 50 % overlap, Hamming)
+at batch = 65,536 frames per GPU (BASELINE.json `metric`).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+A "step" is one pass of the hot path (jdsp_stft_i16_dev: int16 framing + window
++ forward transform, full 1024-bin complex64 spectrum) over one batch of
+synthetic PCM that is already resident in HBM.  For N > 1 the driver launches
+one rank per GPU with torch.distributed.run; frames are independent, so every
+rank transforms its own shard of N*65,536 frames (weak scaling, no data-path
+collective); `--gather` additionally times an RCCL all_gather of the spectra and
+reports it separately (never part of `value`).
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+N_FFT, HOP, FRAMES_PER_GPU = 1024, 512, 65536
+BYTES_PER_FRAME = 512 * 2 + 1024 * 8          # 9,216 B algorithmic
+HBM_PEAK_GBS = 8000.0                         # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def synth_pcm(rank, n_frames):
+    """SURVEY.md §8d synthetic input: default_rng(0).normal(0,3000) int16, (B+1)*512 samples.
+    Rank r takes frames [r*B, (r+1)*B) of the global stream: its slice plus a 512-sample halo."""
+    import numpy as np
+    rng = np.random.default_rng(0)
+    total = 512 * (n_frames * (rank + 1) + 1)
+    x = np.clip(np.rint(rng.normal(0.0, 3000.0, total)), -32768, 32767).astype(np.int16)
+    return x[512 * n_frames * rank:]
+
+
+def cpu_baseline(seconds=10.0):
+    """The oracle (CPU restatement of the reference algorithm, FP64, per-frame
+    window recomputation, single thread like the reference) on a bounded sample."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+    orc = oracle_lib.load_oracle()
+    chunk = 4096
+    pcm = synth_pcm(0, chunk)
+    orc.stft(pcm, 64)                              # warm the twiddle cache
+    done, t0 = 0, time.perf_counter()
+    while True:
+        orc.stft(pcm, chunk)
+        done += chunk
+        dt = time.perf_counter() - t0
+        if dt >= seconds:
+            break
+    one = done / dt
+    # all host cores: frames are independent, static partition over threads (ctypes drops the GIL)
+    import threading
+    cores = os.cpu_count() or 1
+    counts = [0] * cores
+    stop = time.perf_counter() + min(seconds, 8.0)
+
+    def work(i):
+        while time.perf_counter() < stop:
+            orc.stft(pcm, chunk)
+            counts[i] += chunk
+
+    t0 = time.perf_counter()
+    th = [threading.Thread(target=work, args=(i,)) for i in range(cores)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    allc = sum(counts) / (time.perf_counter() - t0)
+    return {"value": one, "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": "%d frames (chunks of %d from the same synthetic stream), FP64 oracle, single thread" % (done, chunk),
+            "all_cores": {"value": allc, "cores": cores}}
+
+
+def read_traffic():
+    """HBM bytes per launch from the committed PMC pass (profiles/r01_stft_pmc.json), or None."""
+    p = os.path.join(ROOT, "profiles", "stft_pmc_traffic.json")
+    try:
+        with open(p) as f:
+            return json.load(f).get("hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--frames", type=int, default=FRAMES_PER_GPU, help="frames per GPU per step")
+    ap.add_argument("--gather", action="store_true", help="also time an RCCL all_gather of the spectra (reported separately)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import jeicyboodsp_amd
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    dev = torch.device("cuda", local_rank)
+
+    eng = jeicyboodsp_amd.Engine(local_rank)
+    B = args.frames
+    pcm = torch.from_numpy(synth_pcm(rank, B)[: 512 * (B + 1)].copy()).to(dev)
+    spec = torch.empty((B, N_FFT), dtype=torch.complex64, device=dev)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        eng.stft(pcm, B, N_FFT, HOP, out=spec)
+    barrier()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for a, b in ev:
+        a.record()
+        eng.stft(pcm, B, N_FFT, HOP, out=spec)
+        b.record()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kern_ms = sum(a.elapsed_time(b) for a, b in ev) / max(len(ev), 1)
+
+    gather_ms = None
+    if args.gather and dist is not None:
+        out = torch.empty((world * B, N_FFT), dtype=torch.complex64, device=dev)
+        dist.all_gather_into_tensor(torch.view_as_real(out), torch.view_as_real(spec))
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(5):
+            dist.all_gather_into_tensor(torch.view_as_real(out), torch.view_as_real(spec))
+        barrier()
+        gather_ms = (time.perf_counter() - t1) / 5 * 1e3
+
+    t = torch.tensor([elapsed, kern_ms], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed, kern_ms = float(t[0]), float(t[1])
+
+    if rank == 0:
+        frames_total = float(B) * world * args.steps
+        value = frames_total / elapsed
+        ach = BYTES_PER_FRAME * B / (kern_ms * 1e-3) / 1e9
+        line = {
+            "metric": "STFT frames/s (1024-pt, 50% OLA)",
+            "value": value,
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "STFT analysis n_fft=1024 hop=512 Hamming, batch=%d frames/GPU, int16 PCM in HBM -> complex64 full spectrum in HBM" % B,
+                       "frames_per_gpu": B, "parallelism": "frame-sharded x%d, no collective" % world},
+            "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": ach / HBM_PEAK_GBS, "traffic": read_traffic(),
+                         "kernel": "stft1024_hop512_kernel<2>", "kernel_ms": kern_ms,
+                         "algorithmic_bytes_per_launch": BYTES_PER_FRAME * B},
+        }
+        if gather_ms is not None:
+            line["gather"] = {"ms": gather_ms, "bytes_per_rank": B * N_FFT * 8,
+                              "frames_per_s_including_gather": float(B) * world / (elapsed / args.steps + gather_ms * 1e-3)}
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+
+    eng.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

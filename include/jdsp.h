@@ -1,0 +1,103 @@
+/*
+ * jdsp.h -- C ABI of the MI355X (gfx950) engine behind JeicybooDSP's FFT-based
+ * spectral path.  Plain C, plain pointers and sizes; no C++/torch types.
+ *
+ * The reference (phoenix163/JeicybooDSP) has no plugin/FFI layer: its seam is
+ * the per-block free function each program's main() calls.  Every entry point
+ * below names the reference function(s) (file:line) whose work it performs for
+ * a whole batch of blocks at once; jeicyboodsp_amd/compat/ keeps the
+ * reference's own per-block C++ signatures on top of this ABI, and
+ * INTEGRATION.md shows the binding a maintainer adds on the reference side.
+ *
+ * Conventions
+ *   - every function returns 0 on success and a negative JDSP_E* code on
+ *     failure, never throws; jdsp_last_error() gives the text for the handle.
+ *   - a jdsp_ctx is confined to one host thread / one stream of audio at a
+ *     time (the reference's functions are non-re-entrant: static state in
+ *     every per-block function, e.g. SpectralSubtraction_final.cpp:202,208-209;
+ *     here that state lives in the handle).
+ *   - "_dev" entry points take DEVICE pointers and only enqueue work on the
+ *     handle's HIP stream (no allocation, no synchronisation: graph-capturable);
+ *     the plain entry points take HOST pointers, copy in, run, copy out and
+ *     synchronise.
+ *   - spectra are interleaved (re, im) float pairs, full length n_fft per frame
+ *     exactly like the reference's fftw_complex[FFT_PROCESSING_SIZE] buffers
+ *     (SpectralSubtraction_final.cpp:205-206), in single precision.
+ */
+#ifndef JDSP_H
+#define JDSP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define JDSP_ABI_VERSION 1
+
+enum {
+    JDSP_OK = 0,
+    JDSP_EINVAL = -1,   /* bad argument / unsupported size */
+    JDSP_EHIP = -2,     /* a HIP runtime call failed */
+    JDSP_ENOMEM = -3,
+    JDSP_ENODEV = -4    /* no gfx950 device / device ordinal out of range */
+};
+
+typedef struct jdsp_ctx jdsp_ctx;
+typedef struct { float re, im; } jdsp_c32;
+
+/* ---- handle ---------------------------------------------------------------- */
+int jdsp_abi_version(void);
+/* Creates a handle on HIP device `device`.  Fails with JDSP_ENODEV when there
+ * is no GPU: there is no CPU fallback in this library. */
+int jdsp_create(int device, jdsp_ctx **out);
+int jdsp_destroy(jdsp_ctx *ctx);
+const char *jdsp_last_error(const jdsp_ctx *ctx);   /* ctx may be NULL: global creation error */
+/* Enqueue on a caller-owned hipStream_t (e.g. the caller framework's current
+ * stream).  The value is used as given: NULL is HIP's default (null) stream.
+ * jdsp_use_own_stream() goes back to the handle's private non-blocking stream. */
+int jdsp_set_stream(jdsp_ctx *ctx, void *hip_stream);
+int jdsp_use_own_stream(jdsp_ctx *ctx);
+/* Tuning knobs, by name; unknown names return JDSP_EINVAL.
+ *   "stft.frames_per_wave"  consecutive frames one wavefront owns (0 = auto) */
+int jdsp_set_option(jdsp_ctx *ctx, const char *name, long value);
+int jdsp_synchronize(jdsp_ctx *ctx);
+/* Device properties the host side sizes launches with. */
+int jdsp_device_info(jdsp_ctx *ctx, int *n_cu, size_t *hbm_bytes, char *name, size_t name_len);
+
+/* Device memory helpers for callers without their own allocator. */
+int jdsp_malloc(jdsp_ctx *ctx, size_t bytes, void **dev_ptr);
+int jdsp_free(jdsp_ctx *ctx, void *dev_ptr);
+int jdsp_memcpy_h2d(jdsp_ctx *ctx, void *dev_dst, const void *host_src, size_t bytes);
+int jdsp_memcpy_d2h(jdsp_ctx *ctx, void *host_dst, const void *dev_src, size_t bytes);
+
+/* ---- FFTAlgorithm_ver2.cpp -------------------------------------------------- */
+/* Bitrev table (FFTAlgorithm_ver2.cpp:186-202), computed on the device with the
+ * reference's 16-bit shift/or loop; bit count from block_len (:188), mask with
+ * n_fft-1 (:202).  table_host: n_fft int16.  Bit-exact. */
+int jdsp_bitrev_table(jdsp_ctx *ctx, int n_fft, int block_len, int16_t *table_host);
+/* Batched FFTProcess (FFTAlgorithm_ver2.cpp:94-149): `batch` independent
+ * n_fft-point complex transforms, interleaved double (COMPLEX, :20-22) in and
+ * out, forward != 0 -> exp(-j..), unnormalised both ways.  Host pointers. */
+int jdsp_fft_process_f64(jdsp_ctx *ctx, const double *in_host, double *out_host,
+                         int n_fft, long batch, int forward);
+int jdsp_fft_process_f64_dev(jdsp_ctx *ctx, const double *in_dev, double *out_dev,
+                             int n_fft, long batch, int forward);
+
+/* ---- STFT analysis: framing + Hamming + forward transform -------------------- */
+/* Replaces, for n_frames frames at once, SpectralSubtraction_final.cpp:218-230
+ * (== WienerFilter_final.cpp:181-193, noise path SS:168-180): frame f =
+ * pcm[hop*f .. hop*f+n_fft) * (0.54-0.46cos(2*3.141592*i/(n_fft-1))) -> unnormalised
+ * forward DFT, all n_fft bins.  pcm must hold hop*(n_frames-1)+n_fft samples.
+ * Supported: n_fft = 1024 with hop = 512 (reference-native, the headline
+ * configuration) and any hop >= 1 for n_fft = 1024. */
+int jdsp_stft_i16_dev(jdsp_ctx *ctx, const int16_t *pcm_dev, long n_frames,
+                      int n_fft, int hop, jdsp_c32 *spec_dev);
+int jdsp_stft_i16(jdsp_ctx *ctx, const int16_t *pcm_host, long n_samples,
+                  int n_fft, int hop, jdsp_c32 *spec_host, long *n_frames_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* JDSP_H */

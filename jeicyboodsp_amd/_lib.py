@@ -1,0 +1,59 @@
+"""ctypes binding of libjdsp.so (the C ABI in include/jdsp.h).
+
+There is no fallback: if the HIP library has not been built, importing this
+module raises, and if there is no gfx950 GPU, creating an Engine raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libjdsp.so")
+
+OK, EINVAL, EHIP, ENOMEM, ENODEV = 0, -1, -2, -3, -4
+
+
+class JdspError(RuntimeError):
+    def __init__(self, code, text):
+        super().__init__("jdsp error %d: %s" % (code, text))
+        self.code = code
+
+
+def _load():
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so.7
+    # (same SONAME as /opt/rocm's).  Load torch's first so that libjdsp.so binds
+    # to the runtime torch's allocator and streams live in; loading them in the
+    # other order leaves torch unable to see the GPU.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "jeicyboodsp_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    vp, i, l, sz = C.c_void_p, C.c_int, C.c_long, C.c_size_t
+    sig = {
+        "jdsp_abi_version": (i, []),
+        "jdsp_create": (i, [i, C.POINTER(vp)]),
+        "jdsp_destroy": (i, [vp]),
+        "jdsp_last_error": (C.c_char_p, [vp]),
+        "jdsp_set_stream": (i, [vp, vp]),
+        "jdsp_use_own_stream": (i, [vp]),
+        "jdsp_set_option": (i, [vp, C.c_char_p, l]),
+        "jdsp_synchronize": (i, [vp]),
+        "jdsp_device_info": (i, [vp, C.POINTER(i), C.POINTER(sz), C.c_char_p, sz]),
+        "jdsp_malloc": (i, [vp, sz, C.POINTER(vp)]),
+        "jdsp_free": (i, [vp, vp]),
+        "jdsp_memcpy_h2d": (i, [vp, vp, vp, sz]),
+        "jdsp_memcpy_d2h": (i, [vp, vp, vp, sz]),
+        "jdsp_stft_i16_dev": (i, [vp, vp, l, i, i, vp]),
+        "jdsp_stft_i16": (i, [vp, vp, l, i, i, vp, C.POINTER(l)]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
+    return lib
+
+
+lib = _load()

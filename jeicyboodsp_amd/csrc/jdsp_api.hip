@@ -1,0 +1,211 @@
+// jdsp_api.hip -- the C ABI (include/jdsp.h) over the gfx950 kernels.
+#include "jdsp_internal.h"
+
+static std::string g_create_error;
+
+namespace jdsp {
+
+int fail(jdsp_ctx *ctx, int code, const char *what, hipError_t e)
+{
+    std::string msg = what ? what : "error";
+    if (e != hipSuccess) {
+        msg += ": ";
+        msg += hipGetErrorString(e);
+    }
+    if (ctx) ctx->error = msg;
+    else g_create_error = msg;
+    return code;
+}
+
+static int ensure_stft1024_table(jdsp_ctx *ctx)
+{
+    if (ctx->stft1024_table) return 0;
+    const int n = stft1024_table_count();
+    std::vector<float2> host((size_t)n);
+    fill_stft1024_table(host.data());
+    JDSP_HIP(ctx, hipMalloc((void **)&ctx->stft1024_table, sizeof(float2) * (size_t)n));
+    JDSP_HIP(ctx, hipMemcpy(ctx->stft1024_table, host.data(), sizeof(float2) * (size_t)n, hipMemcpyHostToDevice));
+    return 0;
+}
+
+}  // namespace jdsp
+
+using jdsp::fail;
+
+extern "C" {
+
+int jdsp_abi_version(void) { return JDSP_ABI_VERSION; }
+
+int jdsp_create(int device, jdsp_ctx **out)
+{
+    if (!out) return fail(nullptr, JDSP_EINVAL, "jdsp_create: out is NULL");
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return fail(nullptr, JDSP_ENODEV, "jdsp_create: no HIP device (this library has no CPU fallback)", e);
+    if (device < 0 || device >= count) return fail(nullptr, JDSP_ENODEV, "jdsp_create: device ordinal out of range");
+    jdsp_ctx *ctx = new (std::nothrow) jdsp_ctx();
+    if (!ctx) return fail(nullptr, JDSP_ENOMEM, "jdsp_create: out of host memory");
+    ctx->device = device;
+    hipDeviceProp_t prop;
+    if ((e = hipSetDevice(device)) != hipSuccess || (e = hipGetDeviceProperties(&prop, device)) != hipSuccess) {
+        delete ctx;
+        return fail(nullptr, JDSP_EHIP, "jdsp_create: device query", e);
+    }
+    ctx->n_cu = prop.multiProcessorCount;
+    ctx->hbm_bytes = prop.totalGlobalMem;
+    snprintf(ctx->name, sizeof(ctx->name), "%s (%s)", prop.name, prop.gcnArchName);
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        std::string m = std::string("jdsp_create: device is ") + prop.gcnArchName + ", this library is built for gfx950 only";
+        delete ctx;
+        return fail(nullptr, JDSP_ENODEV, m.c_str());
+    }
+    if ((e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking)) != hipSuccess) {
+        delete ctx;
+        return fail(nullptr, JDSP_EHIP, "jdsp_create: hipStreamCreate", e);
+    }
+    ctx->stream = ctx->own_stream;
+    *out = ctx;
+    return JDSP_OK;
+}
+
+int jdsp_destroy(jdsp_ctx *ctx)
+{
+    if (!ctx) return JDSP_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->stft1024_table) (void)hipFree(ctx->stft1024_table);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+    return JDSP_OK;
+}
+
+const char *jdsp_last_error(const jdsp_ctx *ctx) { return ctx ? ctx->error.c_str() : g_create_error.c_str(); }
+
+int jdsp_set_stream(jdsp_ctx *ctx, void *hip_stream)
+{
+    if (!ctx) return JDSP_EINVAL;
+    ctx->stream = (hipStream_t)hip_stream;
+    return JDSP_OK;
+}
+
+int jdsp_use_own_stream(jdsp_ctx *ctx)
+{
+    if (!ctx) return JDSP_EINVAL;
+    ctx->stream = ctx->own_stream;
+    return JDSP_OK;
+}
+
+int jdsp_set_option(jdsp_ctx *ctx, const char *name, long value)
+{
+    if (!ctx || !name) return JDSP_EINVAL;
+    if (!strcmp(name, "stft.frames_per_wave")) {
+        if (value < 0 || value > 4096) return fail(ctx, JDSP_EINVAL, "stft.frames_per_wave out of range");
+        ctx->opt_stft_fpw = (int)value;
+        return JDSP_OK;
+    }
+    return fail(ctx, JDSP_EINVAL, "jdsp_set_option: unknown option");
+}
+
+int jdsp_synchronize(jdsp_ctx *ctx)
+{
+    if (!ctx) return JDSP_EINVAL;
+    JDSP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return JDSP_OK;
+}
+
+int jdsp_device_info(jdsp_ctx *ctx, int *n_cu, size_t *hbm_bytes, char *name, size_t name_len)
+{
+    if (!ctx) return JDSP_EINVAL;
+    if (n_cu) *n_cu = ctx->n_cu;
+    if (hbm_bytes) *hbm_bytes = ctx->hbm_bytes;
+    if (name && name_len) snprintf(name, name_len, "%s", ctx->name);
+    return JDSP_OK;
+}
+
+int jdsp_malloc(jdsp_ctx *ctx, size_t bytes, void **dev_ptr)
+{
+    if (!ctx || !dev_ptr) return JDSP_EINVAL;
+    JDSP_HIP(ctx, hipSetDevice(ctx->device));
+    hipError_t e = hipMalloc(dev_ptr, bytes ? bytes : 1);
+    if (e == hipErrorOutOfMemory) return fail(ctx, JDSP_ENOMEM, "jdsp_malloc", e);
+    if (e != hipSuccess) return fail(ctx, JDSP_EHIP, "jdsp_malloc", e);
+    return JDSP_OK;
+}
+
+int jdsp_free(jdsp_ctx *ctx, void *dev_ptr)
+{
+    if (!ctx) return JDSP_EINVAL;
+    JDSP_HIP(ctx, hipFree(dev_ptr));
+    return JDSP_OK;
+}
+
+int jdsp_memcpy_h2d(jdsp_ctx *ctx, void *dev_dst, const void *host_src, size_t bytes)
+{
+    if (!ctx) return JDSP_EINVAL;
+    JDSP_HIP(ctx, hipMemcpyAsync(dev_dst, host_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    JDSP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return JDSP_OK;
+}
+
+int jdsp_memcpy_d2h(jdsp_ctx *ctx, void *host_dst, const void *dev_src, size_t bytes)
+{
+    if (!ctx) return JDSP_EINVAL;
+    JDSP_HIP(ctx, hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    JDSP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return JDSP_OK;
+}
+
+/* ---- STFT ------------------------------------------------------------------ */
+int jdsp_stft_i16_dev(jdsp_ctx *ctx, const int16_t *pcm_dev, long n_frames, int n_fft, int hop, jdsp_c32 *spec_dev)
+{
+    if (!ctx) return JDSP_EINVAL;
+    if (n_fft != 1024) return fail(ctx, JDSP_EINVAL, "jdsp_stft_i16_dev: n_fft must be 1024");
+    if (hop < 1) return fail(ctx, JDSP_EINVAL, "jdsp_stft_i16_dev: hop must be >= 1");
+    if (n_frames < 0 || (n_frames > 0 && (!pcm_dev || !spec_dev)))
+        return fail(ctx, JDSP_EINVAL, "jdsp_stft_i16_dev: bad buffer");
+    if (n_frames == 0) return JDSP_OK;
+    if ((uintptr_t)pcm_dev & 1u) return fail(ctx, JDSP_EINVAL, "jdsp_stft_i16_dev: pcm must be 2-byte aligned");
+    if ((uintptr_t)spec_dev & 15u) return fail(ctx, JDSP_EINVAL, "jdsp_stft_i16_dev: spec must be 16-byte aligned");
+    JDSP_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = jdsp::ensure_stft1024_table(ctx);
+    if (rc) return rc;
+    if (jdsp::launch_stft1024(ctx->stream, ctx->n_cu, ctx->opt_stft_fpw, pcm_dev, n_frames, hop, (float2 *)spec_dev, ctx->stft1024_table))
+        return fail(ctx, JDSP_EHIP, "stft1024 launch", hipGetLastError());
+    return JDSP_OK;
+}
+
+int jdsp_stft_i16(jdsp_ctx *ctx, const int16_t *pcm_host, long n_samples, int n_fft, int hop, jdsp_c32 *spec_host,
+                  long *n_frames_out)
+{
+    if (!ctx) return JDSP_EINVAL;
+    if (n_fft != 1024 || hop < 1) return fail(ctx, JDSP_EINVAL, "jdsp_stft_i16: unsupported n_fft/hop");
+    long n_frames = n_samples >= n_fft ? (n_samples - n_fft) / hop + 1 : 0;
+    if (n_frames_out) *n_frames_out = n_frames;
+    if (n_frames == 0) return JDSP_OK;
+    if (!pcm_host || !spec_host) return fail(ctx, JDSP_EINVAL, "jdsp_stft_i16: NULL buffer");
+    JDSP_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t in_bytes = sizeof(int16_t) * (size_t)((n_frames - 1) * hop + n_fft);
+    const size_t out_bytes = sizeof(jdsp_c32) * (size_t)n_frames * (size_t)n_fft;
+    int16_t *d_in = nullptr;
+    jdsp_c32 *d_out = nullptr;
+    JDSP_HIP(ctx, hipMalloc((void **)&d_in, in_bytes));
+    hipError_t e = hipMalloc((void **)&d_out, out_bytes);
+    if (e != hipSuccess) {
+        (void)hipFree(d_in);
+        return fail(ctx, e == hipErrorOutOfMemory ? JDSP_ENOMEM : JDSP_EHIP, "jdsp_stft_i16: hipMalloc", e);
+    }
+    int rc = JDSP_OK;
+    if ((e = hipMemcpyAsync(d_in, pcm_host, in_bytes, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess)
+        rc = fail(ctx, JDSP_EHIP, "jdsp_stft_i16: H2D", e);
+    if (!rc) rc = jdsp_stft_i16_dev(ctx, d_in, n_frames, n_fft, hop, d_out);
+    if (!rc && (e = hipMemcpyAsync(spec_host, d_out, out_bytes, hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess)
+        rc = fail(ctx, JDSP_EHIP, "jdsp_stft_i16: D2H", e);
+    if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess && !rc) rc = fail(ctx, JDSP_EHIP, "jdsp_stft_i16: sync", e);
+    (void)hipFree(d_in);
+    (void)hipFree(d_out);
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,93 @@
+"""GPU parity: batched STFT analysis (libjdsp.so through the C ABI) against the
+CPU oracle on identical seeded PCM.  Tolerance: 1e-5 relative to the frame's
+peak magnitude (BASELINE.json north_star / SURVEY.md §8d)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+
+
+def _pcm(seed, n, sigma=3000.0):
+    rng = np.random.default_rng(seed)
+    return np.clip(np.rint(rng.normal(0.0, sigma, n)), -32768, 32767).astype(np.int16)
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import jeicyboodsp_amd
+    e = jeicyboodsp_amd.Engine(0)
+    yield e
+    e.close()
+
+
+def _check(spec, want):
+    peak = np.abs(want).max(axis=1, keepdims=True)
+    peak[peak == 0] = 1.0
+    err = np.abs(spec - want) / peak
+    assert err.max() < TOL, err.max()
+
+
+@pytest.mark.parametrize("n_frames", [1, 2, 3, 17, 64, 257, 1000])
+def test_stft_host_path_matches_oracle(eng, oracle, n_frames):
+    pcm = _pcm(n_frames, 512 * (n_frames + 1))
+    got = eng.stft(pcm)
+    assert got.shape == (n_frames, 1024)
+    _check(got.astype(np.complex128), oracle.stft(pcm, n_frames))
+
+
+def test_stft_device_path_and_hermitian(eng, oracle):
+    import torch
+    n_frames = 4099                      # ragged: not a multiple of frames-per-wave
+    pcm = _pcm(11, 512 * (n_frames + 1))
+    d = torch.from_numpy(pcm).cuda()
+    spec = eng.stft(d, n_frames)
+    torch.cuda.synchronize()
+    got = spec.cpu().numpy().astype(np.complex128)
+    idx = np.r_[0:40, n_frames - 40:n_frames, 2000:2040]
+    want = oracle.stft(pcm[: 512 * (n_frames + 1)], n_frames)[idx] if n_frames <= 5000 else None
+    _check(got[idx], want)
+    # real input => X[N-k] = conj(X[k]) for every frame (size-independent property)
+    peak = np.abs(got).max(axis=1, keepdims=True)
+    assert (np.abs(got[:, 1:512] - np.conj(got[:, :512:-1])) / peak).max() < 2e-6
+    assert np.all(got[:, 0].imag == 0) and np.all(got[:, 512].imag == 0)
+
+
+@pytest.mark.parametrize("hop", [160, 256, 333, 1024])
+def test_stft_generic_hop(eng, oracle, hop):
+    n_frames = 37
+    pcm = _pcm(hop, hop * (n_frames - 1) + 1024)
+    got = eng.stft(pcm, hop=hop)
+    _check(got.astype(np.complex128), oracle.stft(pcm, n_frames, 1024, hop))
+
+
+def test_stft_edge_inputs(eng, oracle):
+    assert eng.stft(np.zeros(1000, np.int16)).shape == (0, 1024)      # shorter than one frame
+    z = eng.stft(np.zeros(2048, np.int16))
+    assert z.shape == (3, 1024) and np.all(z == 0)
+    full = np.full(1536, 32767, np.int16)
+    full[::2] = -32768                                              # extreme alternating samples
+    _check(eng.stft(full).astype(np.complex128), oracle.stft(full, 2))
+
+
+def test_stft_full_batch_properties(eng):
+    """BASELINE size (65,536 frames): linearity and Parseval, no oracle needed."""
+    import torch
+    n_frames = 65536
+    pcm = _pcm(0, 512 * (n_frames + 1))
+    d = torch.from_numpy(pcm).cuda()
+    spec = eng.stft(d, n_frames)
+    torch.cuda.synchronize()
+    # Parseval per frame: sum|X|^2 = N * sum (x w)^2
+    i = np.arange(1024)
+    w = 0.54 - 0.46 * np.cos(2 * 3.141592 * i / 1023)
+    e_spec = (spec.real.double() ** 2 + spec.imag.double() ** 2).sum(dim=1).cpu().numpy()
+    frames = np.lib.stride_tricks.sliding_window_view(pcm, 1024)[::512][:n_frames]
+    e_time = 1024.0 * np.einsum("fi,i->f", frames.astype(np.float64) ** 2, w ** 2)
+    assert np.abs(e_spec / e_time - 1).max() < 1e-5
+    # frame f's spectrum must not depend on which wave/chunk computed it: recompute a slice alone
+    lo = 12345
+    part = eng.stft(d[512 * lo: 512 * (lo + 8 + 1)], 8)
+    torch.cuda.synchronize()
+    assert torch.equal(part, spec[lo:lo + 8])
