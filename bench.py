@@ -174,7 +174,7 @@ def main():
                        "frames_per_gpu": B, "parallelism": "frame-sharded x%d, no collective" % world},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": read_traffic(),
-                         "kernel": "stft1024_hop512_kernel<2>", "kernel_ms": kern_ms,
+                         "kernel": "stft1024_hop512_kernel<1>", "kernel_ms": kern_ms,
                          "algorithmic_bytes_per_launch": BYTES_PER_FRAME * B},
         }
         if gather_ms is not None:

@@ -97,6 +97,43 @@ int jdsp_stft_i16_dev(jdsp_ctx *ctx, const int16_t *pcm_dev, long n_frames,
 int jdsp_stft_i16(jdsp_ctx *ctx, const int16_t *pcm_host, long n_samples,
                   int n_fft, int hop, jdsp_c32 *spec_host, long *n_frames_out);
 
+/* ---- spectral subtraction / Wiener filter ------------------------------------- */
+/* One jdsp_denoise object holds everything the reference keeps in static locals
+ * for one audio stream: main()'s run-length counter and noise estimate
+ * (SpectralSubtraction_final.cpp:70-72), EstimateNoiseSpectrum's running
+ * average (:161), the keep buffers (:164,:208), the overlap buffer (:209) and
+ * the call counters (:202).  Feeding a stream in batches of any size -- down to
+ * the reference's one 512-sample block per call -- yields the same output.
+ *
+ * jdsp_denoise_process* replaces, for n_blocks blocks, one iteration each of
+ * main()'s loop: VoiceActivityDetection (SS:121-156 / WF:261-296),
+ * EstimateNoiseSpectrum (SS:159-198 / WF:120-159) and SpectralSubtraction
+ * (SS:201-264) or WienerFiltering (WF:162-235).  Like the reference, the first
+ * two blocks of a stream produce no output (SS:260-263): *n_out_blocks =
+ * jdsp_denoise_blocks_out().  out gets n_out blocks of 512 int16; precast (may
+ * be NULL) gets the same samples before the (short) cast, as float. */
+enum { JDSP_SPECSUB = 0, JDSP_WIENER = 1 };
+typedef struct jdsp_denoise jdsp_denoise;
+int jdsp_denoise_create(jdsp_ctx *ctx, int mode, jdsp_denoise **out);
+int jdsp_denoise_destroy(jdsp_denoise *h);
+int jdsp_denoise_reset(jdsp_denoise *h);                       /* back to a fresh stream */
+int jdsp_denoise_set_option(jdsp_denoise *h, const char *name, long value);   /* "blocks_per_wave" */
+long jdsp_denoise_blocks_out(const jdsp_denoise *h, long n_blocks);
+/* Sizes the device workspace for batches of up to max_blocks (the only call
+ * that allocates; process() calls it on demand). */
+int jdsp_denoise_reserve(jdsp_denoise *h, long max_blocks);
+int jdsp_denoise_process_dev(jdsp_denoise *h, const int16_t *pcm_dev, long n_blocks, int16_t *out_dev,
+                             float *precast_dev, long *n_out_blocks);
+int jdsp_denoise_process(jdsp_denoise *h, const int16_t *pcm_host, long n_blocks, int16_t *out_host,
+                         float *precast_host, long *n_out_blocks);
+/* Current rgdEstimatedNS (1024 doubles, host).  Synchronises. */
+int jdsp_denoise_noise(jdsp_denoise *h, double *noise_host);
+/* VoiceActivityDetection results of the first n blocks of the last process call:
+ * voice flag, sum of squared truncated samples (dEnergy*1024, SS:135) and dZCR (SS:140).
+ * Any pointer may be NULL.  Synchronises. */
+int jdsp_denoise_vad_trace(jdsp_denoise *h, long n, uint8_t *voice_host, int64_t *energy_sum_host,
+                           int32_t *zcr_host);
+
 #ifdef __cplusplus
 }
 #endif

@@ -47,6 +47,19 @@ def _load():
         "jdsp_free": (i, [vp, vp]),
         "jdsp_memcpy_h2d": (i, [vp, vp, vp, sz]),
         "jdsp_memcpy_d2h": (i, [vp, vp, vp, sz]),
+        "jdsp_bitrev_table": (i, [vp, i, i, vp]),
+        "jdsp_fft_process_f64": (i, [vp, vp, vp, i, l, i]),
+        "jdsp_fft_process_f64_dev": (i, [vp, vp, vp, i, l, i]),
+        "jdsp_denoise_create": (i, [vp, i, C.POINTER(vp)]),
+        "jdsp_denoise_destroy": (i, [vp]),
+        "jdsp_denoise_reset": (i, [vp]),
+        "jdsp_denoise_set_option": (i, [vp, C.c_char_p, l]),
+        "jdsp_denoise_blocks_out": (l, [vp, l]),
+        "jdsp_denoise_reserve": (i, [vp, l]),
+        "jdsp_denoise_process_dev": (i, [vp, vp, l, vp, vp, C.POINTER(l)]),
+        "jdsp_denoise_process": (i, [vp, vp, l, vp, vp, C.POINTER(l)]),
+        "jdsp_denoise_noise": (i, [vp, vp]),
+        "jdsp_denoise_vad_trace": (i, [vp, l, vp, vp, vp]),
         "jdsp_stft_i16_dev": (i, [vp, vp, l, i, i, vp]),
         "jdsp_stft_i16": (i, [vp, vp, l, i, i, vp, C.POINTER(l)]),
     }

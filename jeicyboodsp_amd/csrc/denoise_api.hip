@@ -1,0 +1,215 @@
+// denoise_api.hip -- C ABI of the spectral-subtraction / Wiener stream object.
+#include "jdsp_internal.h"
+
+using jdsp::fail;
+
+static void free_workspace(jdsp_denoise *h)
+{
+    void *p[] = {h->flags, h->nrun, h->ver, h->events, h->dbg_energy, h->dbg_zcr, h->mag, h->rows};
+    for (void *q : p)
+        if (q) (void)hipFree(q);
+    h->flags = nullptr;
+    h->nrun = h->ver = h->events = nullptr;
+    h->dbg_energy = nullptr;
+    h->dbg_zcr = nullptr;
+    h->mag = h->rows = nullptr;
+    h->cap_blocks = 0;
+}
+
+extern "C" {
+
+int jdsp_denoise_create(jdsp_ctx *ctx, int mode, jdsp_denoise **out)
+{
+    if (!ctx || !out) return JDSP_EINVAL;
+    *out = nullptr;
+    if (mode != JDSP_SPECSUB && mode != JDSP_WIENER) return fail(ctx, JDSP_EINVAL, "jdsp_denoise_create: mode");
+    JDSP_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = jdsp::ensure_stft1024_table(ctx);
+    if (rc) return rc;
+    jdsp_denoise *h = new (std::nothrow) jdsp_denoise();
+    if (!h) return fail(ctx, JDSP_ENOMEM, "jdsp_denoise_create");
+    h->ctx = ctx;
+    h->mode = mode;
+    hipError_t e = hipSuccess;
+    for (int i = 0; i < 2 && e == hipSuccess; i++) e = hipMalloc((void **)&h->st[i], sizeof(jdsp::DenoiseState));
+    if (e == hipSuccess) e = hipMalloc((void **)&h->plan, sizeof(jdsp::DenoisePlan));
+    if (e == hipSuccess) e = hipMalloc((void **)&h->w_hi, sizeof(double) * 512);
+    if (e == hipSuccess) {
+        double w[512];
+        for (int i = 0; i < 512; i++) w[i] = (0.54 - 0.46 * cos(2 * 3.141592 * (512 + i) / (1024 - 1)));   // SS:131
+        e = hipMemcpy(h->w_hi, w, sizeof(w), hipMemcpyHostToDevice);
+    }
+    if (e != hipSuccess) {
+        jdsp_denoise_destroy(h);
+        return fail(ctx, JDSP_EHIP, "jdsp_denoise_create: alloc", e);
+    }
+    rc = jdsp_denoise_reset(h);
+    if (rc) {
+        jdsp_denoise_destroy(h);
+        return rc;
+    }
+    *out = h;
+    return JDSP_OK;
+}
+
+int jdsp_denoise_destroy(jdsp_denoise *h)
+{
+    if (!h) return JDSP_OK;
+    (void)hipSetDevice(h->ctx->device);
+    (void)hipStreamSynchronize(h->ctx->stream);
+    free_workspace(h);
+    for (int i = 0; i < 2; i++)
+        if (h->st[i]) (void)hipFree(h->st[i]);
+    if (h->plan) (void)hipFree(h->plan);
+    if (h->w_hi) (void)hipFree(h->w_hi);
+    delete h;
+    return JDSP_OK;
+}
+
+int jdsp_denoise_reset(jdsp_denoise *h)
+{
+    if (!h) return JDSP_EINVAL;
+    jdsp_ctx *ctx = h->ctx;
+    for (int i = 0; i < 2; i++) JDSP_HIP(ctx, hipMemsetAsync(h->st[i], 0, sizeof(jdsp::DenoiseState), ctx->stream));
+    h->calls = 0;
+    h->cur = 0;
+    h->last_blocks = 0;
+    return JDSP_OK;
+}
+
+int jdsp_denoise_set_option(jdsp_denoise *h, const char *name, long value)
+{
+    if (!h || !name) return JDSP_EINVAL;
+    if (!strcmp(name, "blocks_per_wave")) {
+        h->opt_k = (int)value;
+        return JDSP_OK;
+    }
+    return fail(h->ctx, JDSP_EINVAL, "jdsp_denoise_set_option: unknown option");
+}
+
+long jdsp_denoise_blocks_out(const jdsp_denoise *h, long n_blocks)
+{
+    if (!h || n_blocks < 0) return 0;
+    const long first_emit = h->calls >= 2 ? 0 : 2 - h->calls;       // SS:260-263
+    return n_blocks > first_emit ? n_blocks - first_emit : 0;
+}
+
+int jdsp_denoise_reserve(jdsp_denoise *h, long max_blocks)
+{
+    if (!h || max_blocks < 0) return JDSP_EINVAL;
+    jdsp_ctx *ctx = h->ctx;
+    if (max_blocks <= h->cap_blocks) return JDSP_OK;
+    JDSP_HIP(ctx, hipSetDevice(ctx->device));
+    JDSP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    free_workspace(h);
+    const size_t n = (size_t)max_blocks;
+    hipError_t e = hipMalloc((void **)&h->flags, n);
+    if (e == hipSuccess) e = hipMalloc((void **)&h->nrun, n * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc((void **)&h->ver, n * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc((void **)&h->events, n * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc((void **)&h->dbg_energy, n * sizeof(long long));
+    if (e == hipSuccess) e = hipMalloc((void **)&h->dbg_zcr, n * sizeof(int));
+    // worst case: every block feeds the noise average; an estimate can latch at most every 10th block
+    if (e == hipSuccess) e = hipMalloc((void **)&h->mag, n * 1024 * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void **)&h->rows, (n / 10 + 2) * 1024 * sizeof(float));
+    if (e != hipSuccess) {
+        free_workspace(h);
+        return fail(ctx, e == hipErrorOutOfMemory ? JDSP_ENOMEM : JDSP_EHIP, "jdsp_denoise_reserve", e);
+    }
+    h->cap_blocks = max_blocks;
+    return JDSP_OK;
+}
+
+int jdsp_denoise_process_dev(jdsp_denoise *h, const int16_t *pcm_dev, long n_blocks, int16_t *out_dev,
+                             float *precast_dev, long *n_out_blocks)
+{
+    if (!h) return JDSP_EINVAL;
+    jdsp_ctx *ctx = h->ctx;
+    if (n_blocks < 0) return fail(ctx, JDSP_EINVAL, "jdsp_denoise_process: n_blocks < 0");
+    const long n_out = jdsp_denoise_blocks_out(h, n_blocks);
+    if (n_out_blocks) *n_out_blocks = n_out;
+    if (n_blocks == 0) return JDSP_OK;
+    if (!pcm_dev || (n_out > 0 && !out_dev)) return fail(ctx, JDSP_EINVAL, "jdsp_denoise_process: NULL buffer");
+    if (((uintptr_t)pcm_dev & 15u) || ((uintptr_t)out_dev & 15u))
+        return fail(ctx, JDSP_EINVAL, "jdsp_denoise_process: buffers must be 16-byte aligned");
+    JDSP_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = jdsp_denoise_reserve(h, n_blocks);      // no-op once sized (call jdsp_denoise_reserve before graph capture)
+    if (rc) return rc;
+    const jdsp::DenoiseState *st_in = h->st[h->cur];
+    jdsp::DenoiseState *st_out = h->st[h->cur ^ 1];
+    hipStream_t s = ctx->stream;
+    if (jdsp::launch_vad(s, pcm_dev, n_blocks, h->w_hi, h->flags, h->dbg_energy, h->dbg_zcr) ||
+        jdsp::launch_denoise_plan(s, h->flags, n_blocks, st_in, st_out, h->nrun, h->ver, h->events, h->plan) ||
+        jdsp::launch_noise_estimate(s, pcm_dev, n_blocks, st_in, st_out, h->events, h->nrun, h->plan,
+                                    ctx->stft1024_table, h->mag, h->rows) ||
+        jdsp::launch_denoise(s, h->mode, h->opt_k, pcm_dev, n_blocks, h->calls, st_in, st_out, h->ver, h->rows,
+                             ctx->stft1024_table, out_dev, precast_dev))
+        return fail(ctx, JDSP_EHIP, "denoise launch", hipGetLastError());
+    h->cur ^= 1;
+    h->calls += n_blocks;
+    h->last_blocks = n_blocks;
+    return JDSP_OK;
+}
+
+int jdsp_denoise_process(jdsp_denoise *h, const int16_t *pcm_host, long n_blocks, int16_t *out_host,
+                         float *precast_host, long *n_out_blocks)
+{
+    if (!h) return JDSP_EINVAL;
+    jdsp_ctx *ctx = h->ctx;
+    if (n_blocks < 0) return fail(ctx, JDSP_EINVAL, "jdsp_denoise_process: n_blocks < 0");
+    const long n_out = jdsp_denoise_blocks_out(h, n_blocks);
+    if (n_out_blocks) *n_out_blocks = n_out;
+    if (n_blocks == 0) return JDSP_OK;
+    if (!pcm_host || (n_out > 0 && !out_host)) return fail(ctx, JDSP_EINVAL, "jdsp_denoise_process: NULL buffer");
+    JDSP_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t in_b = (size_t)n_blocks * 512 * sizeof(int16_t);
+    const size_t out_b = (size_t)(n_out > 0 ? n_out : 1) * 512 * sizeof(int16_t);
+    int16_t *d_in = nullptr, *d_out = nullptr;
+    float *d_pre = nullptr;
+    hipError_t e = hipMalloc((void **)&d_in, in_b);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_out, out_b);
+    if (e == hipSuccess && precast_host) e = hipMalloc((void **)&d_pre, out_b * 2);
+    int rc = JDSP_OK;
+    if (e != hipSuccess) rc = fail(ctx, JDSP_ENOMEM, "jdsp_denoise_process: hipMalloc", e);
+    if (!rc && (e = hipMemcpyAsync(d_in, pcm_host, in_b, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess)
+        rc = fail(ctx, JDSP_EHIP, "jdsp_denoise_process: H2D", e);
+    if (!rc) rc = jdsp_denoise_process_dev(h, d_in, n_blocks, d_out, d_pre, nullptr);
+    if (!rc && n_out > 0 &&
+        (e = hipMemcpyAsync(out_host, d_out, (size_t)n_out * 1024, hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess)
+        rc = fail(ctx, JDSP_EHIP, "jdsp_denoise_process: D2H", e);
+    if (!rc && n_out > 0 && precast_host &&
+        (e = hipMemcpyAsync(precast_host, d_pre, (size_t)n_out * 2048, hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess)
+        rc = fail(ctx, JDSP_EHIP, "jdsp_denoise_process: D2H", e);
+    if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess && !rc) rc = fail(ctx, JDSP_EHIP, "jdsp_denoise_process: sync", e);
+    if (d_in) (void)hipFree(d_in);
+    if (d_out) (void)hipFree(d_out);
+    if (d_pre) (void)hipFree(d_pre);
+    return rc;
+}
+
+int jdsp_denoise_noise(jdsp_denoise *h, double *noise_host)
+{
+    if (!h || !noise_host) return JDSP_EINVAL;
+    jdsp_ctx *ctx = h->ctx;
+    float tmp[1024];
+    JDSP_HIP(ctx, hipMemcpyAsync(tmp, h->st[h->cur]->noise, sizeof(tmp), hipMemcpyDeviceToHost, ctx->stream));
+    JDSP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < 1024; i++) noise_host[i] = tmp[i];
+    return JDSP_OK;
+}
+
+int jdsp_denoise_vad_trace(jdsp_denoise *h, long n, uint8_t *voice_host, int64_t *energy_sum_host, int32_t *zcr_host)
+{
+    if (!h) return JDSP_EINVAL;
+    jdsp_ctx *ctx = h->ctx;
+    if (n < 0 || n > h->last_blocks) return fail(ctx, JDSP_EINVAL, "jdsp_denoise_vad_trace: n exceeds the last call");
+    if (n == 0) return JDSP_OK;
+    if (voice_host) JDSP_HIP(ctx, hipMemcpyAsync(voice_host, h->flags, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    if (energy_sum_host)
+        JDSP_HIP(ctx, hipMemcpyAsync(energy_sum_host, h->dbg_energy, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (zcr_host) JDSP_HIP(ctx, hipMemcpyAsync(zcr_host, h->dbg_zcr, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    JDSP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return JDSP_OK;
+}
+
+}  // extern "C"

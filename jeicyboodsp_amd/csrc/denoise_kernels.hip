@@ -1,0 +1,457 @@
+// denoise_kernels.hip -- SpectralSubtraction_final.cpp / WienerFilter_final.cpp on gfx950.
+//
+// The reference runs one 512-sample block at a time through a chain of functions with
+// static state (SS:92-113).  Here a whole batch of blocks goes through five launches:
+//
+//   vad_kernel          A11  VoiceActivityDetection per block (SS:121-156): integer/FP64, bit-exact
+//   plan_kernel         A13  main()'s run-length counter (SS:98-109) as a prefix scan: run length
+//                            n[j], the list of blocks that call EstimateNoiseSpectrum (n >= 2) and,
+//                            per block, which latched estimate (n == 10, SS:189-193) is current
+//   noise_mag_kernel    A12  |FFT(window * [previous block, block])| for the listed blocks (SS:168-183)
+//   noise_scan_kernel   A12  the running average (SS:182-187), sequential over the list, one bin per thread
+//   denoise_kernel      A8/A9/A10  window -> FFT -> gain -> IFFT -> overlap-add -> (short), fused;
+//                            one wavefront owns K consecutive output blocks and recomputes one halo frame
+//
+// All of the reference's statics live in DenoiseState (ping-ponged between calls so a launch
+// never reads state it is also writing), which makes batches of any size -- down to the
+// reference's one block per call -- produce the same stream.
+#include "frame_io.h"
+#include "jdsp_internal.h"
+
+namespace jdsp {
+
+// ---------------------------------------------------------------------------------------
+// A11.  frame = [zeros(512), block] because the keep buffer is never updated (SS:154 is
+// unreachable); s = (short)(x * w) truncates; E = sum s^2 / 1024; Z counts s[i]*x[i+1] < 0
+// (the next sample is not windowed yet, SS:139).  E > 700 <=> sum s^2 > 716800 exactly.
+__global__ __launch_bounds__(64) void vad_kernel(const short *__restrict__ pcm, long n_blocks,
+                                                 const double *__restrict__ w_hi, unsigned char *__restrict__ flags,
+                                                 long long *__restrict__ dbg_energy, int *__restrict__ dbg_zcr)
+{
+    const long b = blockIdx.x;
+    const int lane = threadIdx.x;
+    if (b >= n_blocks) return;
+    const u32x4 img = reinterpret_cast<const u32x4 *>(pcm + b * 512)[lane];
+    int x[9];
+    x[0] = (short)(img.x & 0xffffu); x[1] = (int)img.x >> 16;
+    x[2] = (short)(img.y & 0xffffu); x[3] = (int)img.y >> 16;
+    x[4] = (short)(img.z & 0xffffu); x[5] = (int)img.z >> 16;
+    x[6] = (short)(img.w & 0xffffu); x[7] = (int)img.w >> 16;
+    x[8] = __shfl_down(x[0], 1);                   // first sample of the next lane
+    if (lane == 63) x[8] = 0;                      // block sample 512 does not exist: frame[1024], defined 0
+    long long e = 0;
+    int z = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const int s = (int)((double)x[k] * w_hi[8 * lane + k]);     // (short)(short * double), in range
+        e += (long long)s * s;
+        z += (s * x[k + 1] < 0) ? 1 : 0;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        e += __shfl_xor(e, o);
+        z += __shfl_xor(z, o);
+    }
+    if (lane == 0) {
+        flags[b] = (e > 716800LL || z < 200) ? 1 : 0;      // SS:147 with THRESHOLD_OF_ENERGY 700, _ZCR 200
+        if (dbg_energy) dbg_energy[b] = e;
+        if (dbg_zcr) dbg_zcr[b] = z;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// A13 bookkeeping.  One workgroup of 1024 threads, each owning a contiguous slice of blocks.
+struct RunSummary { int has_voice, trailing; };
+
+__device__ __forceinline__ RunSummary combine(RunSummary a, RunSummary b)
+{
+    RunSummary r;
+    r.has_voice = a.has_voice | b.has_voice;
+    r.trailing = b.has_voice ? b.trailing : a.trailing + b.trailing;
+    return r;
+}
+
+__global__ __launch_bounds__(1024) void plan_kernel(const unsigned char *__restrict__ flags, long n_blocks,
+                                                    const DenoiseState *__restrict__ st_in, DenoiseState *st_out,
+                                                    int *__restrict__ nrun, int *__restrict__ ver,
+                                                    int *__restrict__ events, DenoisePlan *plan)
+{
+    __shared__ RunSummary sum[1024];
+    __shared__ int cnt_ev[1024], cnt_sn[1024];
+    const int t = threadIdx.x;
+    const long chunk = (n_blocks + 1023) / 1024;
+    const long a = (long)t * chunk;
+    const long b = a + chunk < n_blocks ? a + chunk : n_blocks;
+
+    RunSummary mine = {0, 0};
+    for (long j = a; j < b; j++) {
+        if (flags[j]) { mine.has_voice = 1; mine.trailing = 0; }
+        else mine.trailing++;
+    }
+    sum[t] = mine;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {                     // inclusive Hillis-Steele scan
+        RunSummary v = sum[t];
+        if (t >= o) v = combine(sum[t - o], v);
+        __syncthreads();
+        sum[t] = v;
+        __syncthreads();
+    }
+    const int run_in = st_in->run_len;
+    int r = run_in;                                           // run length entering my slice
+    if (t > 0) r = sum[t - 1].has_voice ? sum[t - 1].trailing : run_in + sum[t - 1].trailing;
+    const int r_start = r;
+
+    int ne = 0, ns = 0;
+    for (long j = a; j < b; j++) {
+        if (flags[j]) r = 0;
+        else {
+            r++;
+            ne += (r >= 2);                                   // SS:103-105
+            ns += (r == 10);                                  // SS:189
+        }
+    }
+    cnt_ev[t] = ne;
+    cnt_sn[t] = ns;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        int ve = cnt_ev[t], vs = cnt_sn[t];
+        if (t >= o) { ve += cnt_ev[t - o]; vs += cnt_sn[t - o]; }
+        __syncthreads();
+        cnt_ev[t] = ve;
+        cnt_sn[t] = vs;
+        __syncthreads();
+    }
+    int eo = cnt_ev[t] - ne, so = cnt_sn[t] - ns;             // exclusive offsets
+    r = r_start;
+    for (long j = a; j < b; j++) {
+        if (flags[j]) { r = 0; nrun[j] = 0; }
+        else {
+            r++;
+            nrun[j] = r;
+            if (r >= 2) events[eo++] = (int)j;
+            if (r == 10) so++;
+        }
+        ver[j] = so;                                          // the estimate latched AT block j already applies to it
+    }
+    if (b == n_blocks && a < b) st_out->run_len = r;
+    if (t == 1023) {
+        plan->n_events = cnt_ev[1023];
+        plan->n_snap = cnt_sn[1023];
+    }
+    if (n_blocks == 0 && t == 0) st_out->run_len = run_in;
+}
+
+// ---------------------------------------------------------------------------------------
+// Loads block j of this call as a 16-byte-per-lane image; block -1 is the previous call's
+// last block (state), anything else outside [0, n_blocks) is silence.
+__device__ __forceinline__ u32x4 load_block(const short *__restrict__ pcm, long n_blocks,
+                                            const DenoiseState *__restrict__ st_in, long j, int lane)
+{
+    u32x4 zero = {0u, 0u, 0u, 0u};
+    if (j >= 0 && j < n_blocks) return reinterpret_cast<const u32x4 *>(pcm + j * 512)[lane];
+    if (j == -1) return reinterpret_cast<const u32x4 *>(st_in->prev)[lane];
+    return zero;
+}
+
+// window -> forward transform -> natural-order image of Zh in LDS
+__device__ __forceinline__ void forward_to_lds(const unsigned int *raw, const FrameTables &t, float2 *lds, int lane)
+{
+    float2 v[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const float2 s = unpack_i16x2(raw[r]);
+        v[r] = make_float2(s.x * t.win[r].x, s.y * t.win[r].y);
+    }
+    wave_fft512<false>(v, lds, lane, t.tw);
+#pragma unroll
+    for (int d = 0; d < 8; d++) lds[lane + 64 * d] = v[d];
+    wave_lds_fence();
+}
+
+// A12, first half: magnitudes of the frames that feed the noise average.
+template <int J>
+__device__ __forceinline__ void mag_store_j(const float2 *lds, int lane, const float2 *wsp, float *dst)
+{
+    const int m = 128 * J + 2 * lane;
+    const float4 zz = *reinterpret_cast<const float4 *>(&lds[m]);
+    const float2 zr0 = lds[(512 - m) & 511];
+    const float2 zr1 = lds[511 - m];
+    float2 lo0, hi0, lo1, hi1;
+    split_fwd<J>(make_float2(zz.x, zz.y), zr0, wsp[0], lo0, hi0);
+    split_fwd<J>(make_float2(zz.z, zz.w), zr1, wsp[1], lo1, hi1);
+    *reinterpret_cast<float2 *>(dst + m) =
+        make_float2(sqrtf(lo0.x * lo0.x + lo0.y * lo0.y), sqrtf(lo1.x * lo1.x + lo1.y * lo1.y));
+    *reinterpret_cast<float2 *>(dst + m + 512) =
+        make_float2(sqrtf(hi0.x * hi0.x + hi0.y * hi0.y), sqrtf(hi1.x * hi1.x + hi1.y * hi1.y));
+}
+
+__global__ __launch_bounds__(64) void noise_mag_kernel(const short *__restrict__ pcm, long n_blocks,
+                                                       const DenoiseState *__restrict__ st_in,
+                                                       const int *__restrict__ events,
+                                                       const DenoisePlan *__restrict__ plan,
+                                                       const float2 *__restrict__ table, float *__restrict__ mag)
+{
+    __shared__ __attribute__((aligned(16))) float2 lds[kWaveLdsComplex];
+    __shared__ __attribute__((aligned(16))) unsigned int stage[256];
+    const int lane = threadIdx.x;
+    const int e = blockIdx.x;
+    if (e >= plan->n_events) return;
+    const long j = events[e];
+    const u32x4 h0 = load_block(pcm, n_blocks, st_in, j - 1, lane);   // rgssKeepBuffer (SS:165-170)
+    const u32x4 h1 = load_block(pcm, n_blocks, st_in, j, lane);
+    FrameTables t;
+    load_frame_tables(t, table, lane);
+    unsigned int raw[8];
+    relayout_half(stage, lane, h0, raw);
+    relayout_half(stage, lane, h1, raw + 4);
+    forward_to_lds(raw, t, lds, lane);
+    float *dst = mag + (size_t)e * 1024;
+    mag_store_j<0>(lds, lane, t.wsp, dst);
+    mag_store_j<1>(lds, lane, t.wsp, dst);
+    mag_store_j<2>(lds, lane, t.wsp, dst);
+    mag_store_j<3>(lds, lane, t.wsp, dst);
+}
+
+// A12, second half: rgsdAveragedNS += |X|; from run length 3 on, /= 2 (SS:182-187); at run
+// length 10 the average is latched (SS:189-193).  noise_rows[0] is the estimate carried in.
+__global__ __launch_bounds__(256) void noise_scan_kernel(const float *__restrict__ mag, const int *__restrict__ events,
+                                                         const int *__restrict__ nrun,
+                                                         const DenoisePlan *__restrict__ plan,
+                                                         const DenoiseState *__restrict__ st_in, DenoiseState *st_out,
+                                                         float *__restrict__ noise_rows)
+{
+    const int bin = blockIdx.x * blockDim.x + threadIdx.x;      // 0..1023
+    float avg = st_in->avg[bin];
+    float cur = st_in->noise[bin];
+    noise_rows[bin] = cur;
+    const int n_events = plan->n_events;
+    int row = 0;
+    for (int e = 0; e < n_events; e++) {
+        const int n = nrun[events[e]];
+        avg += mag[(size_t)e * 1024 + bin];
+        if (n >= 3) avg *= 0.5f;
+        if (n == 10) {
+            row++;
+            cur = avg;
+            noise_rows[(size_t)row * 1024 + bin] = cur;
+        }
+    }
+    st_out->avg[bin] = avg;
+    st_out->noise[bin] = cur;
+}
+
+// ---------------------------------------------------------------------------------------
+// A8 (SS:233-242): Y = (|X| - N) e^{j phase(X)}; no clamp at zero; X == 0 -> phase 0 -> (-N, 0).
+// A9 (WF:196-213): Y = |X| (1 - min(1, N^2/|X|^2)) e^{j phase(X)}; 0/0 stays NaN as in the reference.
+template <int MODE>
+__device__ __forceinline__ float2 apply_gain(float2 x, float n)
+{
+    const float p = x.x * x.x + x.y * x.y;
+    if (MODE == 0) {
+        const float mag = sqrtf(p);
+        if (mag == 0.0f) return make_float2(-n, 0.0f);
+        const float g = (mag - n) / mag;
+        return make_float2(x.x * g, x.y * g);
+    } else {
+        float r = (n * n) / p;
+        if (r >= 1.0f) r = 1.0f;
+        const float g = 1.0f - r;
+        return make_float2(x.x * g, x.y * g);
+    }
+}
+
+template <int MODE, int J>
+__device__ __forceinline__ void gain_presplit_j(const float2 *lds, float2 *zout, int lane, const float2 *wsp,
+                                                const float *__restrict__ noise)
+{
+    const int m = 128 * J + 2 * lane;
+    const float4 zz = *reinterpret_cast<const float4 *>(&lds[m]);
+    const float2 zr0 = lds[(512 - m) & 511];
+    const float2 zr1 = lds[511 - m];
+    const float2 nlo = *reinterpret_cast<const float2 *>(noise + m);
+    const float2 nhi = *reinterpret_cast<const float2 *>(noise + m + 512);
+    float2 lo0, hi0, lo1, hi1;
+    split_fwd<J>(make_float2(zz.x, zz.y), zr0, wsp[0], lo0, hi0);
+    split_fwd<J>(make_float2(zz.z, zz.w), zr1, wsp[1], lo1, hi1);
+    lo0 = apply_gain<MODE>(lo0, nlo.x); hi0 = apply_gain<MODE>(hi0, nhi.x);
+    lo1 = apply_gain<MODE>(lo1, nlo.y); hi1 = apply_gain<MODE>(hi1, nhi.y);
+    zout[2 * J] = presplit_inv<J>(lo0, hi0, wsp[0]);
+    zout[2 * J + 1] = presplit_inv<J>(lo1, hi1, wsp[1]);
+}
+
+// One frame: samples -> y = IDFT(gain(DFT(window * frame))) / 1024, returned in the
+// transform layout: y[d] = (y[2 lane + 128 d], y[2 lane + 128 d + 1]).
+template <int MODE>
+__device__ __forceinline__ void denoise_frame(const unsigned int *raw, const FrameTables &t, float2 *lds, int lane,
+                                              const float *__restrict__ noise, float2 (&y)[8])
+{
+    forward_to_lds(raw, t, lds, lane);
+    float2 z[8];
+    gain_presplit_j<MODE, 0>(lds, z, lane, t.wsp, noise);
+    gain_presplit_j<MODE, 1>(lds, z, lane, t.wsp, noise);
+    gain_presplit_j<MODE, 2>(lds, z, lane, t.wsp, noise);
+    gain_presplit_j<MODE, 3>(lds, z, lane, t.wsp, noise);
+    wave_lds_fence();
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+        *reinterpret_cast<float4 *>(&lds[128 * j + 2 * lane]) = make_float4(z[2 * j].x, z[2 * j].y, z[2 * j + 1].x, z[2 * j + 1].y);
+    wave_lds_fence();
+#pragma unroll
+    for (int r = 0; r < 8; r++) y[r] = lds[lane + 64 * r];
+    wave_lds_fence();
+    wave_fft512<true>(y, lds, lane, t.tw);
+    // the reference's 1/N after FFTW's unnormalised inverse (SS:248); a power of two, exact
+#pragma unroll
+    for (int d = 0; d < 8; d++) y[d] = make_float2(y[d].x * (1.0f / 1024.0f), y[d].y * (1.0f / 1024.0f));
+    wave_lds_fence();
+}
+
+#ifndef JDSP_DENOISE_MINWAVES
+#define JDSP_DENOISE_MINWAVES 3
+#endif
+
+template <int MODE, int K>
+__global__ __launch_bounds__(64, JDSP_DENOISE_MINWAVES) void denoise_kernel(
+    const short *__restrict__ pcm, long n_blocks, long calls_before, const DenoiseState *__restrict__ st_in,
+    DenoiseState *st_out, const int *__restrict__ ver, const float *__restrict__ noise_rows,
+    const float2 *__restrict__ table, short *__restrict__ out, float *__restrict__ precast)
+{
+    __shared__ __attribute__((aligned(16))) float2 lds[kWaveLdsComplex];
+    __shared__ __attribute__((aligned(16))) unsigned int stage[256];
+    const int lane = threadIdx.x;
+    const long per_xcd = (gridDim.x + 7) >> 3;                // XCD-aware chunk order (speed only)
+    const long j0 = ((long)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3)) * K;
+    if (j0 >= n_blocks) return;
+
+    u32x4 half[K + 2];                                        // blocks j0-2 .. j0+K-1
+#pragma unroll
+    for (int h = 0; h < K + 2; h++) half[h] = load_block(pcm, n_blocks, st_in, j0 - 2 + h, lane);
+    FrameTables t;
+    load_frame_tables(t, table, lane);
+
+    const long first_emit = calls_before >= 2 ? 0 : 2 - calls_before;   // SS:260-263: calls 1 and 2 emit nothing
+    unsigned int raw[8];
+    float2 tail[4], y[8];
+    relayout_half(stage, lane, half[0], raw);
+    relayout_half(stage, lane, half[1], raw + 4);
+    if (j0 == 0) {
+        // rgsdOveraped[512..1023] carried over from the previous call
+#pragma unroll
+        for (int d = 0; d < 4; d++) tail[d] = *reinterpret_cast<const float2 *>(&st_in->tail[2 * lane + 128 * d]);
+    } else if (calls_before + j0 - 1 == 0) {
+        // the very first call of a stream only stashes its block (SS:211-216): no output, empty overlap
+#pragma unroll
+        for (int d = 0; d < 4; d++) tail[d] = make_float2(0.f, 0.f);
+    } else {
+        denoise_frame<MODE>(raw, t, lds, lane, noise_rows + (size_t)ver[j0 - 1] * 1024, y);   // halo frame
+#pragma unroll
+        for (int d = 0; d < 4; d++) tail[d] = y[d + 4];
+    }
+
+#pragma unroll
+    for (int i = 0; i < K; i++) {
+        const long j = j0 + i;
+        if (j >= n_blocks) break;
+#pragma unroll
+        for (int r = 0; r < 4; r++) raw[r] = raw[r + 4];
+        relayout_half(stage, lane, half[i + 2], raw + 4);
+        if (calls_before + j == 0) {
+#pragma unroll
+            for (int d = 0; d < 8; d++) y[d] = make_float2(0.f, 0.f);
+        } else {
+            denoise_frame<MODE>(raw, t, lds, lane, noise_rows + (size_t)ver[j] * 1024, y);
+        }
+        float2 o[4];
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+            o[d] = make_float2(tail[d].x + y[d].x, tail[d].y + y[d].y);      // SS:248 overlap-add
+            tail[d] = y[d + 4];                                               // SS:255-256
+        }
+        if (j >= first_emit) {
+            const long oi = j - first_emit;
+#pragma unroll
+            for (int d = 0; d < 4; d++) stage[lane + 64 * d] = cast_i16_bits(o[d].x) | (cast_i16_bits(o[d].y) << 16);
+            wave_lds_fence();
+            const u32x4 img = reinterpret_cast<const u32x4 *>(stage)[lane];
+            wave_lds_fence();
+            __builtin_nontemporal_store(img, reinterpret_cast<u32x4 *>(out + oi * 512) + lane);
+            if (precast) {
+#pragma unroll
+                for (int d = 0; d < 4; d++) *reinterpret_cast<float2 *>(precast + oi * 512 + 2 * lane + 128 * d) = o[d];
+            }
+        }
+        if (j == n_blocks - 1) {
+            reinterpret_cast<u32x4 *>(st_out->prev)[lane] = half[i + 2];        // SS:257
+#pragma unroll
+            for (int d = 0; d < 4; d++) *reinterpret_cast<float2 *>(&st_out->tail[2 * lane + 128 * d]) = tail[d];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+int launch_vad(hipStream_t s, const short *pcm, long n_blocks, const double *w_hi, unsigned char *flags,
+               long long *dbg_energy, int *dbg_zcr)
+{
+    if (n_blocks <= 0) return 0;
+    hipLaunchKernelGGL(vad_kernel, dim3((unsigned)n_blocks), dim3(64), 0, s, pcm, n_blocks, w_hi, flags, dbg_energy,
+                       dbg_zcr);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+int launch_denoise_plan(hipStream_t s, const unsigned char *flags, long n_blocks, const DenoiseState *st_in,
+                        DenoiseState *st_out, int *nrun, int *ver, int *events, DenoisePlan *plan)
+{
+    hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(1024), 0, s, flags, n_blocks, st_in, st_out, nrun, ver, events,
+                       plan);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+int launch_noise_estimate(hipStream_t s, const short *pcm, long n_blocks, const DenoiseState *st_in,
+                          DenoiseState *st_out, const int *events, const int *nrun, const DenoisePlan *plan,
+                          const float2 *table, float *mag, float *noise_rows)
+{
+    if (n_blocks > 0)
+        hipLaunchKernelGGL(noise_mag_kernel, dim3((unsigned)n_blocks), dim3(64), 0, s, pcm, n_blocks, st_in, events,
+                           plan, table, mag);
+    hipLaunchKernelGGL(noise_scan_kernel, dim3(4), dim3(256), 0, s, mag, events, nrun, plan, st_in, st_out,
+                       noise_rows);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+template <int MODE, int K>
+static void launch_dn(hipStream_t s, const short *pcm, long n_blocks, long calls_before, const DenoiseState *st_in,
+                      DenoiseState *st_out, const int *ver, const float *noise_rows, const float2 *table, short *out,
+                      float *precast)
+{
+    long grid = ((n_blocks + K - 1) / K + 7) / 8 * 8;
+    hipLaunchKernelGGL((denoise_kernel<MODE, K>), dim3((unsigned)grid), dim3(64), 0, s, pcm, n_blocks, calls_before,
+                       st_in, st_out, ver, noise_rows, table, out, precast);
+}
+
+int launch_denoise(hipStream_t s, int mode, int k_opt, const short *pcm, long n_blocks, long calls_before,
+                   const DenoiseState *st_in, DenoiseState *st_out, const int *ver, const float *noise_rows,
+                   const float2 *table, short *out, float *precast)
+{
+    if (n_blocks <= 0) return 0;
+#define JDSP_DN(M, KK) launch_dn<M, KK>(s, pcm, n_blocks, calls_before, st_in, st_out, ver, noise_rows, table, out, precast)
+    if (mode == 0) {
+        switch (k_opt) {
+        case 1: JDSP_DN(0, 1); break;
+        case 2: JDSP_DN(0, 2); break;
+        case 8: JDSP_DN(0, 8); break;
+        default: JDSP_DN(0, 4); break;
+        }
+    } else {
+        switch (k_opt) {
+        case 1: JDSP_DN(1, 1); break;
+        case 2: JDSP_DN(1, 2); break;
+        case 8: JDSP_DN(1, 8); break;
+        default: JDSP_DN(1, 4); break;
+        }
+    }
+#undef JDSP_DN
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+}  // namespace jdsp

@@ -1,0 +1,90 @@
+// frame_io.h -- shared pieces of the 1024-point real-frame kernels (gfx950):
+// table layout, int16 unpacking, the forward split and the inverse pre-split.
+#pragma once
+#include "wave_fft512.h"
+
+namespace jdsp {
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// handle-owned table (float2 units), built by fill_stft1024_table():
+//   [0, kTwCount)            wave twiddles (wave_fft512.h)
+//   [kStftWin, +512)         0.5*w[2i], 0.5*w[2i+1]   Hamming, PI = 3.141592 as the reference
+//   [kStftSplit, +512)       W^m = exp(-2*pi*j*m/1024)
+//   [kStftWinFull, +512)     w[2i], w[2i+1]           (not halved; MFCC/debug)
+constexpr int kStftWin = kTwCount;
+constexpr int kStftSplit = kStftWin + 512;
+constexpr int kStftWinFull = kStftSplit + 512;
+constexpr int kStftTableCount = kStftWinFull + 512;
+
+__device__ __forceinline__ float2 unpack_i16x2(unsigned int raw)
+{
+    return make_float2((float)(short)(raw & 0xffffu), (float)((int)raw >> 16));
+}
+
+// (short)double of the reference (e.g. SpectralSubtraction_final.cpp:252): truncate toward
+// zero, keep the low 16 bits (what x86 does for in-int32-range values); NaN -> 0.
+__device__ __forceinline__ unsigned int cast_i16_bits(float v)
+{
+    return (unsigned int)((int)v) & 0xffffu;
+}
+
+// Forward split of the packed transform: Zh = FFT512(z)/2 (the 1/2 is folded into the
+// window).  E = Zh[m] + conj(Zh[512-m]),  O = -j (Zh[m] - conj(Zh[512-m])),
+// X[m] = E + W^m O,  X[m+512] = E - W^m O, with W^m = w_8^j * wsp (m = 128 j + 2 lane + e).
+template <int J>
+__device__ __forceinline__ void split_fwd(float2 zm, float2 zr, float2 wsp, float2 &lo, float2 &hi)
+{
+    const float2 e = make_float2(zm.x + zr.x, zm.y - zr.y);
+    const float2 o = make_float2(zm.y + zr.y, zr.x - zm.x);
+    float2 t = cmul(wsp, o);
+    if (J == 1) t = rot45<false>(t);
+    if (J == 2) t = rot90<false>(t);
+    if (J == 3) t = rot135<false>(t);
+    lo = cadd(e, t);
+    hi = csub(e, t);
+}
+
+// Inverse pre-split: from Y[m] and Y[m+512] of a Hermitian spectrum,
+// Z'[m] = (Y[m] + Y[m+512]) + j (Y[m] - Y[m+512]) conj(W^m); then
+// y[2n] + j y[2n+1] = IDFT512_unnormalised(Z')[n] / 1024.
+template <int J>
+__device__ __forceinline__ float2 presplit_inv(float2 ylo, float2 yhi, float2 wsp)
+{
+    const float2 s = cadd(ylo, yhi);
+    float2 d = csub(ylo, yhi);
+    if (J == 1) d = rot45<true>(d);
+    if (J == 2) d = rot90<true>(d);
+    if (J == 3) d = rot135<true>(d);
+    d = cmul_conj(d, wsp);
+    return make_float2(s.x - d.y, s.y + d.x);     // s + j d
+}
+
+struct FrameTables {
+    WaveTwiddles tw;
+    float2 win[8];     // per lane: window pair of samples (2 lane + 128 r, +1), halved
+    float2 wsp[2];     // W^(2 lane), W^(2 lane + 1)
+};
+
+__device__ __forceinline__ void load_frame_tables(FrameTables &t, const float2 *__restrict__ table, int lane)
+{
+    load_wave_twiddles(t.tw, table, lane);
+#pragma unroll
+    for (int r = 0; r < 8; r++) t.win[r] = table[kStftWin + lane + 64 * r];
+    t.wsp[0] = table[kStftSplit + 2 * lane];
+    t.wsp[1] = table[kStftSplit + 2 * lane + 1];
+}
+
+// Re-lays a half-frame out from the 16-byte-per-lane load image (lane holds samples
+// 8 lane .. 8 lane + 7) to the transform's layout (lane gets the pairs 2 lane + 128 r, r < 4).
+__device__ __forceinline__ void relayout_half(unsigned int *stage, int lane, u32x4 img, unsigned int *out4)
+{
+    reinterpret_cast<u32x4 *>(stage)[lane] = img;
+    wave_lds_fence();
+#pragma unroll
+    for (int r = 0; r < 4; r++) out4[r] = stage[lane + 64 * r];
+    wave_lds_fence();
+}
+
+}  // namespace jdsp

@@ -17,7 +17,7 @@ int fail(jdsp_ctx *ctx, int code, const char *what, hipError_t e)
     return code;
 }
 
-static int ensure_stft1024_table(jdsp_ctx *ctx)
+int ensure_stft1024_table(jdsp_ctx *ctx)
 {
     if (ctx->stft1024_table) return 0;
     const int n = stft1024_table_count();
@@ -76,6 +76,8 @@ int jdsp_destroy(jdsp_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->stft1024_table) (void)hipFree(ctx->stft1024_table);
+    for (auto &p : ctx->c2c_tw)
+        if (p) (void)hipFree(p);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
     return JDSP_OK;
@@ -155,6 +157,80 @@ int jdsp_memcpy_d2h(jdsp_ctx *ctx, void *host_dst, const void *dev_src, size_t b
     JDSP_HIP(ctx, hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
     JDSP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return JDSP_OK;
+}
+
+/* ---- FFTAlgorithm_ver2 -------------------------------------------------------- */
+static int ilog2_exact(int n)
+{
+    int b = 0;
+    while ((1 << b) < n) b++;
+    return (1 << b) == n ? b : -1;
+}
+
+int jdsp_bitrev_table(jdsp_ctx *ctx, int n_fft, int block_len, int16_t *table_host)
+{
+    if (!ctx) return JDSP_EINVAL;
+    if (n_fft < 1 || n_fft > 32768 || block_len < 1 || !table_host)
+        return fail(ctx, JDSP_EINVAL, "jdsp_bitrev_table: bad argument");
+    JDSP_HIP(ctx, hipSetDevice(ctx->device));
+    const int bits = (int)log2((double)block_len);       // FFTAlgorithm_ver2.cpp:188
+    short *d = nullptr;
+    JDSP_HIP(ctx, hipMalloc((void **)&d, sizeof(short) * (size_t)n_fft));
+    int rc = JDSP_OK;
+    hipError_t e;
+    if (jdsp::launch_bitrev_table(ctx->stream, d, n_fft, bits)) rc = fail(ctx, JDSP_EHIP, "bitrev launch", hipGetLastError());
+    if (!rc && (e = hipMemcpyAsync(table_host, d, sizeof(short) * (size_t)n_fft, hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess)
+        rc = fail(ctx, JDSP_EHIP, "jdsp_bitrev_table: D2H", e);
+    if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess && !rc) rc = fail(ctx, JDSP_EHIP, "jdsp_bitrev_table: sync", e);
+    (void)hipFree(d);
+    return rc;
+}
+
+int jdsp_fft_process_f64_dev(jdsp_ctx *ctx, const double *in_dev, double *out_dev, int n_fft, long batch, int forward)
+{
+    if (!ctx) return JDSP_EINVAL;
+    const int lg = ilog2_exact(n_fft);
+    if (lg < 1 || lg > 13) return fail(ctx, JDSP_EINVAL, "jdsp_fft_process_f64: n_fft must be a power of two in [2, 8192]");
+    if (batch < 0 || (batch > 0 && (!in_dev || !out_dev))) return fail(ctx, JDSP_EINVAL, "jdsp_fft_process_f64: bad buffer");
+    if (batch == 0) return JDSP_OK;
+    JDSP_HIP(ctx, hipSetDevice(ctx->device));
+    if (!ctx->c2c_tw[lg]) {
+        std::vector<double2> host((size_t)n_fft / 2 + 1);
+        jdsp::fill_c2c_twiddles(host.data(), n_fft);
+        JDSP_HIP(ctx, hipMalloc((void **)&ctx->c2c_tw[lg], sizeof(double2) * host.size()));
+        JDSP_HIP(ctx, hipMemcpy(ctx->c2c_tw[lg], host.data(), sizeof(double2) * host.size(), hipMemcpyHostToDevice));
+    }
+    if (jdsp::launch_fft_process_f64(ctx->stream, (const double2 *)in_dev, (double2 *)out_dev, n_fft, lg, batch, forward,
+                                     ctx->c2c_tw[lg]))
+        return fail(ctx, JDSP_EHIP, "fft_process_f64 launch", hipGetLastError());
+    return JDSP_OK;
+}
+
+int jdsp_fft_process_f64(jdsp_ctx *ctx, const double *in_host, double *out_host, int n_fft, long batch, int forward)
+{
+    if (!ctx) return JDSP_EINVAL;
+    if (batch < 0 || n_fft < 2) return fail(ctx, JDSP_EINVAL, "jdsp_fft_process_f64: bad argument");
+    if (batch == 0) return JDSP_OK;
+    if (!in_host || !out_host) return fail(ctx, JDSP_EINVAL, "jdsp_fft_process_f64: NULL buffer");
+    JDSP_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t bytes = sizeof(double) * 2 * (size_t)n_fft * (size_t)batch;
+    double *d_in = nullptr, *d_out = nullptr;
+    JDSP_HIP(ctx, hipMalloc((void **)&d_in, bytes));
+    hipError_t e = hipMalloc((void **)&d_out, bytes);
+    if (e != hipSuccess) {
+        (void)hipFree(d_in);
+        return fail(ctx, JDSP_ENOMEM, "jdsp_fft_process_f64: hipMalloc", e);
+    }
+    int rc = JDSP_OK;
+    if ((e = hipMemcpyAsync(d_in, in_host, bytes, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess)
+        rc = fail(ctx, JDSP_EHIP, "jdsp_fft_process_f64: H2D", e);
+    if (!rc) rc = jdsp_fft_process_f64_dev(ctx, d_in, d_out, n_fft, batch, forward);
+    if (!rc && (e = hipMemcpyAsync(out_host, d_out, bytes, hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess)
+        rc = fail(ctx, JDSP_EHIP, "jdsp_fft_process_f64: D2H", e);
+    if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess && !rc) rc = fail(ctx, JDSP_EHIP, "jdsp_fft_process_f64: sync", e);
+    (void)hipFree(d_in);
+    (void)hipFree(d_out);
+    return rc;
 }
 
 /* ---- STFT ------------------------------------------------------------------ */

@@ -22,9 +22,21 @@ struct jdsp_ctx {
     int opt_stft_fpw = 0;              // 0 = auto
     // device tables, created on first use
     float2 *stft1024_table = nullptr;
+    double2 *c2c_tw[16] = {nullptr};   // by log2(n_fft)
 };
 
 namespace jdsp {
+
+// All of the reference's static state for one SS/Wiener stream (device memory).
+struct DenoiseState {
+    int run_len;          // main(): iNumOfIteration                      SS:72,99,108
+    int pad[3];
+    float avg[1024];      // EstimateNoiseSpectrum: rgsdAveragedNS         SS:161
+    float noise[1024];    // main(): rgdEstimatedNS                        SS:70
+    short prev[512];      // the keep buffers = previous input block       SS:164,208
+    float tail[512];      // rgsdOveraped[0..511] after the shift          SS:209,255
+};
+struct DenoisePlan { int n_events, n_snap, pad0, pad1; };
 
 int fail(jdsp_ctx *ctx, int code, const char *what, hipError_t e = hipSuccess);
 
@@ -40,4 +52,43 @@ void fill_stft1024_table(float2 *host_table);
 int launch_stft1024(hipStream_t stream, int n_cu, int fpw_opt, const short *pcm, long n_frames, long hop, float2 *spec,
                     const float2 *table);
 
+
+// fft_c2c_kernels.hip
+int launch_bitrev_table(hipStream_t stream, short *table_dev, int n_fft, int bits);
+int launch_fft_process_f64(hipStream_t stream, const double2 *in, double2 *out, int n_fft, int log2n, long batch,
+                           int forward, const double2 *tw);
+void fill_c2c_twiddles(double2 *t, int n_fft);
+
+
+// denoise_kernels.hip
+int launch_vad(hipStream_t s, const short *pcm, long n_blocks, const double *w_hi, unsigned char *flags,
+               long long *dbg_energy, int *dbg_zcr);
+int launch_denoise_plan(hipStream_t s, const unsigned char *flags, long n_blocks, const DenoiseState *st_in,
+                        DenoiseState *st_out, int *nrun, int *ver, int *events, DenoisePlan *plan);
+int launch_noise_estimate(hipStream_t s, const short *pcm, long n_blocks, const DenoiseState *st_in,
+                          DenoiseState *st_out, const int *events, const int *nrun, const DenoisePlan *plan,
+                          const float2 *table, float *mag, float *noise_rows);
+int launch_denoise(hipStream_t s, int mode, int k_opt, const short *pcm, long n_blocks, long calls_before,
+                   const DenoiseState *st_in, DenoiseState *st_out, const int *ver, const float *noise_rows,
+                   const float2 *table, short *out, float *precast);
+int ensure_stft1024_table(jdsp_ctx *ctx);
+
 }  // namespace jdsp
+
+struct jdsp_denoise {
+    jdsp_ctx *ctx = nullptr;
+    int mode = 0;
+    long calls = 0;                       // blocks consumed so far (the reference's call counters)
+    jdsp::DenoiseState *st[2] = {nullptr, nullptr};
+    int cur = 0;                          // st[cur] is the state the next call reads
+    double *w_hi = nullptr;               // second half of the FP64 Hamming window (VAD)
+    long cap_blocks = 0;                  // workspace capacity
+    unsigned char *flags = nullptr;
+    int *nrun = nullptr, *ver = nullptr, *events = nullptr;
+    long long *dbg_energy = nullptr;
+    int *dbg_zcr = nullptr;
+    jdsp::DenoisePlan *plan = nullptr;
+    float *mag = nullptr, *rows = nullptr;
+    long last_blocks = 0;
+    int opt_k = 0;
+};

@@ -4,61 +4,44 @@
 // WienerFilter_final.cpp:181-193): int16 -> double, * Hamming, 1024-point
 // forward c2c DFT of the real frame, all 1024 bins kept.
 //
-// Mapping: one wavefront owns `frames_per_wave` CONSECUTIVE frames.  With
-// hop = 512 the second half of frame f is the first half of frame f+1 and,
-// in the "lane + 64 r" layout, lands in the same lane -- so after the first
-// frame a wave loads only the 512 new samples (4 dwords per lane) and every
-// PCM sample is read from HBM exactly once.  The 8 KB spectrum leaves as eight
-// fully coalesced 1 KB wave stores.  HBM-bound: 1 KB in + 8 KB out per frame.
+// Mapping: one wavefront owns K consecutive frames (K = 1 by default).  A frame
+// is a 512-point complex FFT in the wave's registers/LDS (wave_fft512.h) plus a
+// split step; the 8 KB spectrum leaves as eight fully coalesced 1 KB
+// nontemporal wave stores.  HBM-bound: 1 KB in + 8 KB out per frame.
+//
+// What the measurements on MI355X said (profiles/r01_*; DESIGN.md "STFT kernel"):
+//   * nontemporal STORES + plain LOADS: 92 us; plain stores 129 us; nontemporal
+//     loads 126-155 us (the half-frame two neighbouring waves share stops hitting L2).
+//   * short waves that issue their stores and end beat a persistent wave that
+//     loops with a prefetch (124 us): vmcnt retires loads and stores in issue
+//     order, so a looping wave that waits for its next input also waits for its
+//     previous spectrum to be acknowledged by HBM.
+//   * XCD-aware block -> chunk mapping (blocks b and b+8 share an XCD's L2):
+//     92 -> 88 us, and PCM over-fetch disappears.
+#include "frame_io.h"
 #include "jdsp_internal.h"
-#include "wave_fft512.h"
 
 namespace jdsp {
 
-// table layout (float2 units) appended after the wave twiddles
-constexpr int kStftWin = kTwCount;            // [512] pairs: 0.5*w[2i], 0.5*w[2i+1]
-constexpr int kStftSplit = kStftWin + 512;    // [512] W^m = exp(-2*pi*j*m/1024)
-constexpr int kStftTableCount = kStftSplit + 512;
-
-__device__ __forceinline__ float2 unpack_i16x2(unsigned int raw)
-{
-    return make_float2((float)(short)(raw & 0xffffu), (float)((int)raw >> 16));
-}
-
-// Split of the packed transform: Zh = FFT512(z)/2 (the 1/2 is folded into the
-// window).  For m in [0,512):  E = Zh[m] + conj(Zh[512-m]),
-// O = -j (Zh[m] - conj(Zh[512-m])),  X[m] = E + W^m O,  X[m+512] = E - W^m O.
-__device__ __forceinline__ void split_pair(float2 zm, float2 zr, float2 w, float2 &lo, float2 &hi)
-{
-    const float2 e = make_float2(zm.x + zr.x, zm.y - zr.y);
-    const float2 o = make_float2(zm.y + zr.y, zr.x - zm.x);
-    const float2 t = cmul(w, o);
-    lo = cadd(e, t);
-    hi = csub(e, t);
-}
-
 // ---- build-time variants (tools/tune_stft.py A/Bs them on the GPU) -------------------
+#ifndef JDSP_STFT_K
+#define JDSP_STFT_K 1             // consecutive frames per wavefront ("stft.frames_per_wave" = 0 picks this)
+#endif
 #ifndef JDSP_STFT_MINWAVES
 #define JDSP_STFT_MINWAVES 4      // __launch_bounds__ 2nd arg: waves per SIMD the register budget must allow
 #endif
-#ifndef JDSP_STFT_K
-#define JDSP_STFT_K 2             // consecutive frames per wavefront (default of "stft.frames_per_wave" = 0)
+#ifndef JDSP_STFT_XCD
+#define JDSP_STFT_XCD 1           // 1: XCD-aware chunk -> block mapping
 #endif
 #ifndef JDSP_STFT_NT_LOAD
-#define JDSP_STFT_NT_LOAD 0       // 1: nontemporal PCM loads
+#define JDSP_STFT_NT_LOAD 0       // 1: nontemporal PCM loads (slower: see above)
 #endif
 #ifndef JDSP_STFT_NT
 #define JDSP_STFT_NT 1            // 1: nontemporal spectrum stores
 #endif
-#ifndef JDSP_STFT_WSP_SMALL
-#define JDSP_STFT_WSP_SMALL 1     // 1: 2 split twiddles per lane + w_8 rotations instead of 8
-#endif
 #ifndef JDSP_STFT_ABLATE
 #define JDSP_STFT_ABLATE 0        // timing-only ablations (1: no stores, 2: no transform); never shipped
 #endif
-
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ void store_spec(float4 *p, float4 v)
 {
@@ -71,58 +54,31 @@ __device__ __forceinline__ void store_spec(float4 *p, float4 v)
 }
 
 // Spectrum of one frame from the natural-order image of Zh in LDS.
-template <bool SMALL>
+template <int J>
+__device__ __forceinline__ void split_store_j(const float2 *lds, int lane, const float2 *wsp, float4 *dst)
+{
+    const int m = 128 * J + 2 * lane;
+    const float4 zz = *reinterpret_cast<const float4 *>(&lds[m]);
+    const float2 zr0 = lds[(512 - m) & 511];
+    const float2 zr1 = lds[511 - m];
+    float2 lo0, hi0, lo1, hi1;
+    split_fwd<J>(make_float2(zz.x, zz.y), zr0, wsp[0], lo0, hi0);
+    split_fwd<J>(make_float2(zz.z, zz.w), zr1, wsp[1], lo1, hi1);
+    store_spec(dst + 64 * J, make_float4(lo0.x, lo0.y, lo1.x, lo1.y));
+    store_spec(dst + 64 * J + 256, make_float4(hi0.x, hi0.y, hi1.x, hi1.y));
+}
+
 __device__ __forceinline__ void split_and_store(const float2 *lds, int lane, const float2 *wsp, float2 *out_frame)
 {
     float4 *dst = reinterpret_cast<float4 *>(out_frame) + lane;
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const int m = 128 * j + 2 * lane;
-        const float4 zz = *reinterpret_cast<const float4 *>(&lds[m]);
-        const float2 zr0 = lds[(512 - m) & 511];
-        const float2 zr1 = lds[511 - m];
-        float2 lo0, hi0, lo1, hi1;
-        if (SMALL) {
-            // W^(128 j + 2 lane + e) = w_8^j * W^(2 lane + e): rotate the odd part instead of the twiddle
-            const float2 e0 = make_float2(zz.x + zr0.x, zz.y - zr0.y), o0 = make_float2(zz.y + zr0.y, zr0.x - zz.x);
-            const float2 e1 = make_float2(zz.z + zr1.x, zz.w - zr1.y), o1 = make_float2(zz.w + zr1.y, zr1.x - zz.z);
-            float2 t0 = cmul(wsp[0], o0), t1 = cmul(wsp[1], o1);
-            if (j == 1) { t0 = rot45<false>(t0); t1 = rot45<false>(t1); }
-            if (j == 2) { t0 = rot90<false>(t0); t1 = rot90<false>(t1); }
-            if (j == 3) { t0 = rot135<false>(t0); t1 = rot135<false>(t1); }
-            lo0 = cadd(e0, t0); hi0 = csub(e0, t0);
-            lo1 = cadd(e1, t1); hi1 = csub(e1, t1);
-        } else {
-            split_pair(make_float2(zz.x, zz.y), zr0, wsp[2 * j], lo0, hi0);
-            split_pair(make_float2(zz.z, zz.w), zr1, wsp[2 * j + 1], lo1, hi1);
-        }
-        store_spec(dst + 64 * j, make_float4(lo0.x, lo0.y, lo1.x, lo1.y));
-        store_spec(dst + 64 * j + 256, make_float4(hi0.x, hi0.y, hi1.x, hi1.y));
-    }
+    split_store_j<0>(lds, lane, wsp, dst);
+    split_store_j<1>(lds, lane, wsp, dst);
+    split_store_j<2>(lds, lane, wsp, dst);
+    split_store_j<3>(lds, lane, wsp, dst);
 }
 
-constexpr int kNWsp = JDSP_STFT_WSP_SMALL ? 2 : 8;
-
-__device__ __forceinline__ void load_split_twiddles(float2 *wsp, const float2 *__restrict__ table, int lane)
-{
-    if (JDSP_STFT_WSP_SMALL) {
-        wsp[0] = table[kStftSplit + 2 * lane];
-        wsp[1] = table[kStftSplit + 2 * lane + 1];
-    } else {
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            wsp[2 * j] = table[kStftSplit + 128 * j + 2 * lane];
-            wsp[2 * j + 1] = table[kStftSplit + 128 * j + 2 * lane + 1];
-        }
-    }
-}
-
-// hop == 512.  One wave owns K consecutive frames = K+1 half-frames of 512 samples; every
-// PCM sample is fetched once (one dwordx4 per lane per half-frame) and ALL loads are issued
-// up front.  That is deliberate: gfx950's vmcnt retires loads and stores in issue order, so a
-// wave that waits for a load issued after a frame's stores also waits for those stores to be
-// acknowledged by HBM (measured: a prefetching loop runs 25-50 % slower than this form, whose
-// waves issue their last stores and simply end; see DESIGN.md "STFT kernel").
+// hop == 512.  One wave owns K consecutive frames = K+1 half-frames of 512 samples; ALL
+// loads are issued up front (one dwordx4 per lane per half-frame), see the header comment.
 template <int K>
 __global__ __launch_bounds__(64, JDSP_STFT_MINWAVES) void stft1024_hop512_kernel(
     const short *__restrict__ pcm, float2 *__restrict__ spec, long n_frames, const float2 *__restrict__ table)
@@ -130,7 +86,15 @@ __global__ __launch_bounds__(64, JDSP_STFT_MINWAVES) void stft1024_hop512_kernel
     __shared__ __attribute__((aligned(16))) float2 lds[kWaveLdsComplex];
     __shared__ __attribute__((aligned(16))) unsigned int stage[256];
     const int lane = threadIdx.x;
+#if JDSP_STFT_XCD
+    // Blocks b and b+8 share an XCD (round-robin dispatch): give each XCD a contiguous run of
+    // chunks so the half-frame two neighbouring waves both need is served by one L2.
+    // Placement only changes speed, never results.
+    const long per_xcd = (gridDim.x + 7) >> 3;
+    const long f0 = ((long)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3)) * K;
+#else
     const long f0 = (long)blockIdx.x * K;
+#endif
     if (f0 >= n_frames) return;
 
     // half-frame h holds samples [512 h, 512 h + 512); the stream has n_frames + 1 of them
@@ -146,22 +110,13 @@ __global__ __launch_bounds__(64, JDSP_STFT_MINWAVES) void stft1024_hop512_kernel
 #endif
     }
 
-    WaveTwiddles tw;
-    load_wave_twiddles(tw, table, lane);
-    float2 win[8], wsp[kNWsp];
-#pragma unroll
-    for (int r = 0; r < 8; r++) win[r] = table[kStftWin + lane + 64 * r];
-    load_split_twiddles(wsp, table, lane);
+    FrameTables t;
+    load_frame_tables(t, table, lane);
 
-    // raw[r]: the int16 pair (2*lane + 128*r, +1) of the frame, re-laid out through LDS from
-    // the 16-byte-per-lane load image.  The second half of frame f is the first half of f+1
-    // and sits in the same lane, so raw[4..7] slide down to raw[0..3].
+    // raw[r]: the int16 pair (2*lane + 128*r, +1) of the frame.  The second half of frame f
+    // is the first half of f+1 and sits in the same lane, so raw[4..7] slide down to raw[0..3].
     unsigned int raw[8];
-    reinterpret_cast<u32x4 *>(stage)[lane] = half[0];
-    wave_lds_fence();
-#pragma unroll
-    for (int r = 0; r < 4; r++) raw[r + 4] = stage[lane + 64 * r];
-    wave_lds_fence();
+    relayout_half(stage, lane, half[0], raw + 4);
 
 #pragma unroll
     for (int i = 0; i < K; i++) {
@@ -170,15 +125,11 @@ __global__ __launch_bounds__(64, JDSP_STFT_MINWAVES) void stft1024_hop512_kernel
         float2 v[8];
 #pragma unroll
         for (int r = 0; r < 4; r++) raw[r] = raw[r + 4];
-        reinterpret_cast<u32x4 *>(stage)[lane] = half[i + 1];
-        wave_lds_fence();
-#pragma unroll
-        for (int r = 0; r < 4; r++) raw[r + 4] = stage[lane + 64 * r];
-        wave_lds_fence();
+        relayout_half(stage, lane, half[i + 1], raw + 4);
 #pragma unroll
         for (int r = 0; r < 8; r++) {
             const float2 s = unpack_i16x2(raw[r]);
-            v[r] = make_float2(s.x * win[r].x, s.y * win[r].y);
+            v[r] = make_float2(s.x * t.win[r].x, s.y * t.win[r].y);
         }
 #if JDSP_STFT_ABLATE == 2   /* timing-only build: no transform, stores only */
         {
@@ -188,7 +139,7 @@ __global__ __launch_bounds__(64, JDSP_STFT_MINWAVES) void stft1024_hop512_kernel
             continue;
         }
 #endif
-        wave_fft512<false>(v, lds, lane, tw);
+        wave_fft512<false>(v, lds, lane, t.tw);
 
         // natural-order image of Zh, then the split reads Zh[m] and Zh[512-m]
 #pragma unroll
@@ -197,7 +148,7 @@ __global__ __launch_bounds__(64, JDSP_STFT_MINWAVES) void stft1024_hop512_kernel
 #if JDSP_STFT_ABLATE == 1   /* timing-only build: transform kept alive, stores never taken */
         if (n_frames < 0)
 #endif
-        split_and_store<JDSP_STFT_WSP_SMALL != 0>(lds, lane, wsp, spec + f * 1024);
+        split_and_store(lds, lane, t.wsp, spec + f * 1024);
         wave_lds_fence();
     }
 }
@@ -213,23 +164,19 @@ __global__ __launch_bounds__(64) void stft1024_anyhop_kernel(const short *__rest
     long f1 = f0 + frames_per_wave;
     if (f1 > n_frames) f1 = n_frames;
     if (f0 >= f1) return;
-    WaveTwiddles tw;
-    load_wave_twiddles(tw, table, lane);
-    float2 win[8], wsp[kNWsp];
-#pragma unroll
-    for (int r = 0; r < 8; r++) win[r] = table[kStftWin + lane + 64 * r];
-    load_split_twiddles(wsp, table, lane);
+    FrameTables t;
+    load_frame_tables(t, table, lane);
     for (long f = f0; f < f1; f++) {
         float2 v[8];
         const short *src = pcm + f * hop + 2 * lane;
 #pragma unroll
         for (int r = 0; r < 8; r++)
-            v[r] = make_float2((float)src[128 * r] * win[r].x, (float)src[128 * r + 1] * win[r].y);
-        wave_fft512<false>(v, lds, lane, tw);
+            v[r] = make_float2((float)src[128 * r] * t.win[r].x, (float)src[128 * r + 1] * t.win[r].y);
+        wave_fft512<false>(v, lds, lane, t.tw);
 #pragma unroll
         for (int d = 0; d < 8; d++) lds[lane + 64 * d] = v[d];
         wave_lds_fence();
-        split_and_store<JDSP_STFT_WSP_SMALL != 0>(lds, lane, wsp, spec + f * 1024);
+        split_and_store(lds, lane, t.wsp, spec + f * 1024);
         wave_lds_fence();
     }
 }
@@ -237,7 +184,10 @@ __global__ __launch_bounds__(64) void stft1024_anyhop_kernel(const short *__rest
 template <int K>
 static void launch_hop512(hipStream_t stream, const short *pcm, long n_frames, float2 *spec, const float2 *table)
 {
-    const long grid = (n_frames + K - 1) / K;
+    long grid = (n_frames + K - 1) / K;
+#if JDSP_STFT_XCD
+    grid = (grid + 7) / 8 * 8;
+#endif
     hipLaunchKernelGGL(stft1024_hop512_kernel<K>, dim3((unsigned)grid), dim3(64), 0, stream, pcm, spec, n_frames,
                        table);
 }
@@ -252,8 +202,6 @@ int launch_stft1024(hipStream_t stream, int n_cu, int fpw_opt, const short *pcm,
         case 2: launch_hop512<2>(stream, pcm, n_frames, spec, table); break;
         case 3: launch_hop512<3>(stream, pcm, n_frames, spec, table); break;
         case 4: launch_hop512<4>(stream, pcm, n_frames, spec, table); break;
-        case 6: launch_hop512<6>(stream, pcm, n_frames, spec, table); break;
-        case 8: launch_hop512<8>(stream, pcm, n_frames, spec, table); break;
         default: launch_hop512<JDSP_STFT_K>(stream, pcm, n_frames, spec, table); break;
         }
     } else {
@@ -284,11 +232,12 @@ void fill_stft1024_table(float2 *t)
             double a = -two_pi * (double)(b * c) / 64.0;
             t[kTwT2 + (c - 1) * 8 + b] = make_float2((float)cos(a), (float)sin(a));
         }
-    // Hamming exactly as the reference writes it (PI 3.141592, SS:52,226), halved for the split
+    // Hamming exactly as the reference writes it (PI 3.141592, SS:52,226); halved copy for the split
     for (int i = 0; i < 512; i++) {
         double w0 = (0.54 - 0.46 * cos(2 * 3.141592 * (2 * i) / (1024 - 1)));
         double w1 = (0.54 - 0.46 * cos(2 * 3.141592 * (2 * i + 1) / (1024 - 1)));
         t[kStftWin + i] = make_float2((float)(0.5 * w0), (float)(0.5 * w1));
+        t[kStftWinFull + i] = make_float2((float)w0, (float)w1);
     }
     for (int m = 0; m < 512; m++) {
         double a = -two_pi * (double)m / 1024.0;

@@ -25,6 +25,7 @@ class Engine:
         if rc != 0:
             raise JdspError(rc, L.jdsp_last_error(None).decode())
         self._h = h
+        self._children = []           # stream objects that hold a pointer to this ctx: destroyed first
         self.device = int(device)
         n_cu, hbm = C.c_int(), C.c_size_t()
         name = C.create_string_buffer(96)
@@ -33,6 +34,8 @@ class Engine:
 
     def close(self):
         if getattr(self, "_h", None):
+            for c in list(self._children):
+                c.close()
             L.jdsp_destroy(self._h)
             self._h = None
 
@@ -53,8 +56,36 @@ class Engine:
     def set_option(self, name, value):
         self._ck(L.jdsp_set_option(self._h, name.encode(), int(value)))
 
+    def denoiser(self, mode):
+        return Denoiser(self, mode)
+
     def synchronize(self):
         self._ck(L.jdsp_synchronize(self._h))
+
+    # ---- FFTAlgorithm_ver2.cpp ------------------------------------------------
+    def bitrev_table(self, n_fft, block_len=None):
+        """Bitrev table (FFTAlgorithm_ver2.cpp:186-202) computed on the device; int16[n_fft]."""
+        t = np.zeros(n_fft, np.int16)
+        self._ck(L.jdsp_bitrev_table(self._h, n_fft, block_len or n_fft, t.ctypes.data_as(C.c_void_p)))
+        return t
+
+    def fft_process(self, x, forward=True):
+        """Batched FFTProcess (FFTAlgorithm_ver2.cpp:94-149): complex128 [..., n_fft], unnormalised."""
+        if _is_torch(x):
+            import torch
+            assert x.is_cuda and x.dtype == torch.complex128 and x.is_contiguous()
+            out = torch.empty_like(x)
+            n = x.shape[-1]
+            self._use_torch_stream()
+            self._ck(L.jdsp_fft_process_f64_dev(self._h, C.c_void_p(x.data_ptr()), C.c_void_p(out.data_ptr()), n,
+                                                x.numel() // n, int(forward)))
+            return out
+        x = np.ascontiguousarray(x, np.complex128)
+        out = np.empty_like(x)
+        n = x.shape[-1]
+        self._ck(L.jdsp_fft_process_f64(self._h, x.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), n,
+                                        x.size // n, int(forward)))
+        return out
 
     # ---- STFT analysis (SS:218-230 / WF:181-193 for a whole batch) ---------
     def stft(self, pcm, n_frames=None, n_fft=1024, hop=512, out=None):
@@ -83,3 +114,78 @@ class Engine:
                                  res.ctypes.data_as(C.c_void_p), C.byref(nf)))
         assert nf.value == want
         return res
+
+
+class Denoiser:
+    """One SS/Wiener audio stream (jdsp_denoise): mirrors main()'s loop of
+    SpectralSubtraction_final.cpp:92-113 / WienerFilter_final.cpp:91-112 for batches of blocks."""
+    SPECSUB, WIENER = 0, 1
+
+    def __init__(self, engine, mode):
+        self.eng = engine
+        h = C.c_void_p()
+        engine._ck(L.jdsp_denoise_create(engine._h, int(mode), C.byref(h)))
+        self._h = h
+        engine._children.append(self)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            L.jdsp_denoise_destroy(self._h)
+            self._h = None
+            if self in self.eng._children:
+                self.eng._children.remove(self)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def reset(self):
+        self.eng._ck(L.jdsp_denoise_reset(self._h))
+
+    def set_option(self, name, value):
+        self.eng._ck(L.jdsp_denoise_set_option(self._h, name.encode(), int(value)))
+
+    def blocks_out(self, n_blocks):
+        return L.jdsp_denoise_blocks_out(self._h, n_blocks)
+
+    def process(self, pcm, want_precast=False):
+        """pcm: int16, a whole number of 512-sample blocks.  numpy -> host path, torch CUDA -> device path.
+        Returns out (int16) or (out, precast float32)."""
+        if _is_torch(pcm):
+            import torch
+            assert pcm.is_cuda and pcm.dtype == torch.int16 and pcm.is_contiguous() and pcm.numel() % 512 == 0
+            nb = pcm.numel() // 512
+            n_out = self.blocks_out(nb)
+            out = torch.empty(max(n_out, 1) * 512, dtype=torch.int16, device=pcm.device)
+            pre = torch.empty(max(n_out, 1) * 512, dtype=torch.float32, device=pcm.device) if want_precast else None
+            self.eng._use_torch_stream()
+            self.eng._ck(L.jdsp_denoise_process_dev(self._h, C.c_void_p(pcm.data_ptr()), nb, C.c_void_p(out.data_ptr()),
+                                                    C.c_void_p(pre.data_ptr()) if want_precast else None, None))
+            out = out[:n_out * 512]
+            return (out, pre[:n_out * 512]) if want_precast else out
+        pcm = np.ascontiguousarray(pcm, np.int16)
+        assert pcm.size % 512 == 0
+        nb = pcm.size // 512
+        n_out = self.blocks_out(nb)
+        out = np.zeros(max(n_out, 1) * 512, np.int16)
+        pre = np.zeros(max(n_out, 1) * 512, np.float32) if want_precast else None
+        got = C.c_long()
+        self.eng._ck(L.jdsp_denoise_process(self._h, pcm.ctypes.data_as(C.c_void_p), nb, out.ctypes.data_as(C.c_void_p),
+                                            pre.ctypes.data_as(C.c_void_p) if want_precast else None, C.byref(got)))
+        assert got.value == n_out
+        return (out[:n_out * 512], pre[:n_out * 512]) if want_precast else out[:n_out * 512]
+
+    def noise(self):
+        n = np.zeros(1024, np.float64)
+        self.eng._ck(L.jdsp_denoise_noise(self._h, n.ctypes.data_as(C.c_void_p)))
+        return n
+
+    def vad_trace(self, n):
+        v = np.zeros(n, np.uint8)
+        e = np.zeros(n, np.int64)
+        z = np.zeros(n, np.int32)
+        self.eng._ck(L.jdsp_denoise_vad_trace(self._h, n, v.ctypes.data_as(C.c_void_p), e.ctypes.data_as(C.c_void_p),
+                                              z.ctypes.data_as(C.c_void_p)))
+        return v, e, z
