@@ -134,6 +134,32 @@ int jdsp_denoise_noise(jdsp_denoise *h, double *noise_host);
 int jdsp_denoise_vad_trace(jdsp_denoise *h, long n, uint8_t *voice_host, int64_t *energy_sum_host,
                            int32_t *zcr_host);
 
+/* ---- MFCC ---------------------------------------------------------------------- */
+/* MFCCFeatureExtraction_auto_version1.cpp.  The #defines at :23-33 become a runtime
+ * configuration; jdsp_mfcc_native_cfg() fills in the reference's values
+ * (window 1024, hop 512, 1024-FFT, first 512 bins, 38 channels over 0..22050 Hz,
+ * 12 cepstra c1..c12, lifter 22, pre-emphasis 0.96).  n_fft may be 1024 or 512
+ * (bins used: n_fft/2), win_len <= n_fft, n_chan <= 64, n_cep <= 32. */
+typedef struct {
+    int win_len, hop, n_fft, n_chan, n_cep, lifter;
+    double half_rate, preemph;
+} jdsp_mfcc_cfg;
+typedef struct jdsp_mfcc jdsp_mfcc;
+int jdsp_mfcc_native_cfg(jdsp_mfcc_cfg *cfg);
+/* Runs MelFilterBankInit (:118-152) on the host for cfg and uploads the tables. */
+int jdsp_mfcc_create(jdsp_ctx *ctx, const jdsp_mfcc_cfg *cfg, jdsp_mfcc **out);
+int jdsp_mfcc_destroy(jdsp_mfcc *h);
+/* MelFilterBankInit's three arrays (host): rgdMelFreqs[n_chan+1], rgdFiBins[n_fft/2],
+ * rgdFilterBank[n_fft/2].  Any pointer may be NULL. */
+int jdsp_mfcc_tables(const jdsp_mfcc *h, double *mel_freqs, int *fi_bins, double *fbank);
+/* MFCCFeatureExtraction (:194-231) for n_frames frames: frame j = win_len samples at
+ * pcm[frame_start[j]] (frame_start NULL: hop*j), x[0] of every frame is 0 as at :208.
+ * feats: n_frames * n_cep doubles -- the reference's on-disk vector format (:99). */
+int jdsp_mfcc_frames_dev(jdsp_mfcc *h, const int16_t *pcm_dev, const int64_t *frame_start_dev, long n_frames,
+                         double *feats_dev);
+int jdsp_mfcc_frames(jdsp_mfcc *h, const int16_t *pcm_host, long n_samples, const int64_t *frame_start_host,
+                     long n_frames, double *feats_host);
+
 #ifdef __cplusplus
 }
 #endif

@@ -12,6 +12,12 @@ LIB_PATH = os.path.join(_HERE, "libjdsp.so")
 OK, EINVAL, EHIP, ENOMEM, ENODEV = 0, -1, -2, -3, -4
 
 
+class MfccCfg(C.Structure):
+    """jdsp_mfcc_cfg (include/jdsp.h)"""
+    _fields_ = [("win_len", C.c_int), ("hop", C.c_int), ("n_fft", C.c_int), ("n_chan", C.c_int),
+                ("n_cep", C.c_int), ("lifter", C.c_int), ("half_rate", C.c_double), ("preemph", C.c_double)]
+
+
 class JdspError(RuntimeError):
     def __init__(self, code, text):
         super().__init__("jdsp error %d: %s" % (code, text))
@@ -60,6 +66,12 @@ def _load():
         "jdsp_denoise_process": (i, [vp, vp, l, vp, vp, C.POINTER(l)]),
         "jdsp_denoise_noise": (i, [vp, vp]),
         "jdsp_denoise_vad_trace": (i, [vp, l, vp, vp, vp]),
+        "jdsp_mfcc_native_cfg": (i, [vp]),
+        "jdsp_mfcc_create": (i, [vp, vp, C.POINTER(vp)]),
+        "jdsp_mfcc_destroy": (i, [vp]),
+        "jdsp_mfcc_tables": (i, [vp, vp, vp, vp]),
+        "jdsp_mfcc_frames_dev": (i, [vp, vp, vp, l, vp]),
+        "jdsp_mfcc_frames": (i, [vp, vp, l, vp, l, vp]),
         "jdsp_stft_i16_dev": (i, [vp, vp, l, i, i, vp]),
         "jdsp_stft_i16": (i, [vp, vp, l, i, i, vp, C.POINTER(l)]),
     }

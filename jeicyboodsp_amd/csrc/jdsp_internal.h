@@ -38,6 +38,17 @@ struct DenoiseState {
 };
 struct DenoisePlan { int n_events, n_snap, pad0, pad1; };
 
+// Device-side view of one MFCC configuration (passed by value to the kernel).
+struct MfccDev {
+    int win_len, hop, n_chan, n_cep, bin_stride;   // bin_stride 2: 512-point bins out of the 1024-point transform
+    float preemph;
+    const float2 *window;        // [512] halved Hamming pairs over win_len, zero beyond
+    const int *mel_start, *mel_len;   // [64]
+    const float *mel_w;          // [max_len][64]
+    const double *dct;           // [n_chan][32]: sqrt(2/C) cos(PI i (k-0.5)/C)
+    const double *lifter_w;      // [32]: 1 + L/2 sin(PI i / L)
+};
+
 int fail(jdsp_ctx *ctx, int code, const char *what, hipError_t e = hipSuccess);
 
 #define JDSP_HIP(ctx, call)                                             \
@@ -72,6 +83,9 @@ int launch_denoise(hipStream_t s, int mode, int k_opt, const short *pcm, long n_
                    const DenoiseState *st_in, DenoiseState *st_out, const int *ver, const float *noise_rows,
                    const float2 *table, short *out, float *precast);
 int ensure_stft1024_table(jdsp_ctx *ctx);
+// mfcc_kernels.hip
+int launch_mfcc(hipStream_t s, const short *pcm, const long long *starts, long n_frames, const MfccDev &p,
+                const float2 *table, double *feats);
 
 }  // namespace jdsp
 
@@ -91,4 +105,13 @@ struct jdsp_denoise {
     float *mag = nullptr, *rows = nullptr;
     long last_blocks = 0;
     int opt_k = 0;
+};
+
+struct jdsp_mfcc {
+    jdsp_ctx *ctx = nullptr;
+    jdsp_mfcc_cfg cfg;
+    jdsp::MfccDev dev;
+    void *blob = nullptr;                 // one device allocation holding every table
+    std::vector<double> mel_freqs, fbank;
+    std::vector<int> fi_bins;
 };

@@ -1,0 +1,187 @@
+// mfcc_api.hip -- C ABI of the MFCC front end; MelFilterBankInit runs here, on the host.
+#include "jdsp_internal.h"
+
+using jdsp::fail;
+
+extern "C" {
+
+int jdsp_mfcc_native_cfg(jdsp_mfcc_cfg *c)
+{
+    if (!c) return JDSP_EINVAL;
+    // MFCCFeatureExtraction_auto_version1.cpp:23-33
+    c->win_len = 1024; c->hop = 512; c->n_fft = 1024; c->n_chan = 38; c->n_cep = 12; c->lifter = 22;
+    c->half_rate = 22050.0; c->preemph = 0.96;
+    return JDSP_OK;
+}
+
+int jdsp_mfcc_create(jdsp_ctx *ctx, const jdsp_mfcc_cfg *cfg, jdsp_mfcc **out)
+{
+    if (!ctx || !cfg || !out) return JDSP_EINVAL;
+    *out = nullptr;
+    const jdsp_mfcc_cfg c = *cfg;
+    if ((c.n_fft != 1024 && c.n_fft != 512) || c.win_len < 2 || c.win_len > c.n_fft || c.hop < 1 || c.n_chan < 1 ||
+        c.n_chan > 64 || c.n_cep < 1 || c.n_cep > 32 || c.lifter < 1 || !(c.half_rate > 0))
+        return fail(ctx, JDSP_EINVAL, "jdsp_mfcc_create: unsupported configuration");
+    JDSP_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = jdsp::ensure_stft1024_table(ctx);
+    if (rc) return rc;
+    jdsp_mfcc *h = new (std::nothrow) jdsp_mfcc();
+    if (!h) return fail(ctx, JDSP_ENOMEM, "jdsp_mfcc_create");
+    h->ctx = ctx;
+    h->cfg = c;
+    const int C = c.n_chan, NB = c.n_fft / 2;
+    const double PI = 3.141592;                                                  // :26
+    // ---- MelFilterBankInit (:118-152), in double like the reference ----
+    h->mel_freqs.assign(C + 1, 0.0);
+    h->fi_bins.assign(NB, 0);
+    h->fbank.assign(NB, 0.0);
+    const double unit = 1127.0 * log(1 + (c.half_rate / 700.0)) / (C + 1);       // :124
+    for (int i = 1; i <= C + 1; i++) h->mel_freqs[i - 1] = 700 * (exp(unit * i / 1127.0) - 1.0);   // :126-129
+    for (int i = 0, k = 0; i < NB; i++) {                                        // :131-137
+        if ((i / (double)(NB - 1)) * c.half_rate > h->mel_freqs[k])
+            if (k < C) k++;
+        h->fi_bins[i] = k;
+    }
+    for (int i = 0; i < NB; i++) {                                               // :139-150
+        const int k = h->fi_bins[i];
+        const double fr = (i / (double)(NB - 1)) * c.half_rate;
+        double v = k == 0 ? (h->mel_freqs[0] - fr) / (h->mel_freqs[0] - 0)
+                          : (h->mel_freqs[k] - fr) / (h->mel_freqs[k] - h->mel_freqs[k - 1]);
+        h->fbank[i] = v < 0 ? 0 : v;
+    }
+    // ---- MelFilterBank (:157-168) as per-channel contiguous bin ranges ----
+    std::vector<int> start(64, 0), len(64, 0);
+    int max_len = 1;
+    for (int ch = 0; ch < C; ch++) {
+        int lo = NB, hi = -1;
+        for (int i = 0; i < NB; i++) {
+            const int k = h->fi_bins[i];
+            const bool hit = (k == ch && k != C) || (k == ch + 1);
+            if (hit) { if (i < lo) lo = i; hi = i; }
+        }
+        if (hi >= lo) { start[ch] = lo; len[ch] = hi - lo + 1; if (len[ch] > max_len) max_len = len[ch]; }
+    }
+    std::vector<float> mel_w((size_t)max_len * 64, 0.f);
+    for (int ch = 0; ch < C; ch++)
+        for (int t = 0; t < len[ch]; t++) {
+            const int i = start[ch] + t, k = h->fi_bins[i];
+            double w = 0.0;
+            if (k == ch + 1) w = h->fbank[i];                     // m[k-1] += fb * |X|        (:164)
+            else if (k == ch && k != C) w = 1 - h->fbank[i];      // m[k]   += (1-fb) * |X|    (:161,:166)
+            mel_w[(size_t)t * 64 + ch] = (float)w;
+        }
+    // ---- DCT (:178-182) and lifter (:189) constants ----
+    std::vector<double> dct((size_t)C * 32, 0.0), lift(32, 0.0);
+    for (int i = 1; i <= c.n_cep; i++) {
+        for (int k = 1; k <= C; k++) dct[(size_t)(k - 1) * 32 + (i - 1)] = sqrt(2.0 / C) * cos(PI * i * (k - 0.5) / (double)C);
+        lift[i - 1] = (1 + 0.5 * c.lifter * sin(PI * i / c.lifter));
+    }
+    // ---- Hamming over win_len (:213), halved for the split, zero beyond ----
+    std::vector<float2> window(512, make_float2(0.f, 0.f));
+    for (int i = 0; i < c.win_len; i++) {
+        const double w = 0.5 * (0.54 - 0.46 * cos(2 * PI * i / (c.win_len - 1)));
+        if (i & 1) window[i >> 1].y = (float)w;
+        else window[i >> 1].x = (float)w;
+    }
+    // ---- one blob ----
+    const size_t o_win = 0, o_start = o_win + sizeof(float2) * 512, o_len = o_start + 64 * sizeof(int),
+                 o_w = o_len + 64 * sizeof(int), o_dct = (o_w + mel_w.size() * sizeof(float) + 15) / 16 * 16,
+                 o_lift = o_dct + dct.size() * sizeof(double), total = o_lift + 32 * sizeof(double);
+    std::vector<char> host(total, 0);
+    memcpy(&host[o_win], window.data(), sizeof(float2) * 512);
+    memcpy(&host[o_start], start.data(), 64 * sizeof(int));
+    memcpy(&host[o_len], len.data(), 64 * sizeof(int));
+    memcpy(&host[o_w], mel_w.data(), mel_w.size() * sizeof(float));
+    memcpy(&host[o_dct], dct.data(), dct.size() * sizeof(double));
+    memcpy(&host[o_lift], lift.data(), 32 * sizeof(double));
+    hipError_t e = hipMalloc(&h->blob, total);
+    if (e == hipSuccess) e = hipMemcpy(h->blob, host.data(), total, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        jdsp_mfcc_destroy(h);
+        return fail(ctx, JDSP_EHIP, "jdsp_mfcc_create: tables", e);
+    }
+    char *b = (char *)h->blob;
+    h->dev.win_len = c.win_len; h->dev.hop = c.hop; h->dev.n_chan = C; h->dev.n_cep = c.n_cep;
+    h->dev.bin_stride = c.n_fft == 512 ? 2 : 1;
+    h->dev.preemph = (float)c.preemph;
+    h->dev.window = (const float2 *)(b + o_win);
+    h->dev.mel_start = (const int *)(b + o_start);
+    h->dev.mel_len = (const int *)(b + o_len);
+    h->dev.mel_w = (const float *)(b + o_w);
+    h->dev.dct = (const double *)(b + o_dct);
+    h->dev.lifter_w = (const double *)(b + o_lift);
+    *out = h;
+    return JDSP_OK;
+}
+
+int jdsp_mfcc_destroy(jdsp_mfcc *h)
+{
+    if (!h) return JDSP_OK;
+    (void)hipSetDevice(h->ctx->device);
+    (void)hipStreamSynchronize(h->ctx->stream);
+    if (h->blob) (void)hipFree(h->blob);
+    delete h;
+    return JDSP_OK;
+}
+
+int jdsp_mfcc_tables(const jdsp_mfcc *h, double *mel_freqs, int *fi_bins, double *fbank)
+{
+    if (!h) return JDSP_EINVAL;
+    if (mel_freqs) memcpy(mel_freqs, h->mel_freqs.data(), h->mel_freqs.size() * sizeof(double));
+    if (fi_bins) memcpy(fi_bins, h->fi_bins.data(), h->fi_bins.size() * sizeof(int));
+    if (fbank) memcpy(fbank, h->fbank.data(), h->fbank.size() * sizeof(double));
+    return JDSP_OK;
+}
+
+int jdsp_mfcc_frames_dev(jdsp_mfcc *h, const int16_t *pcm_dev, const int64_t *frame_start_dev, long n_frames,
+                         double *feats_dev)
+{
+    if (!h) return JDSP_EINVAL;
+    jdsp_ctx *ctx = h->ctx;
+    if (n_frames < 0 || (n_frames > 0 && (!pcm_dev || !feats_dev))) return fail(ctx, JDSP_EINVAL, "jdsp_mfcc_frames: bad buffer");
+    if (n_frames == 0) return JDSP_OK;
+    JDSP_HIP(ctx, hipSetDevice(ctx->device));
+    if (jdsp::launch_mfcc(ctx->stream, pcm_dev, (const long long *)frame_start_dev, n_frames, h->dev, ctx->stft1024_table,
+                          feats_dev))
+        return fail(ctx, JDSP_EHIP, "mfcc launch", hipGetLastError());
+    return JDSP_OK;
+}
+
+int jdsp_mfcc_frames(jdsp_mfcc *h, const int16_t *pcm_host, long n_samples, const int64_t *frame_start_host,
+                     long n_frames, double *feats_host)
+{
+    if (!h) return JDSP_EINVAL;
+    jdsp_ctx *ctx = h->ctx;
+    if (n_frames < 0 || n_samples < 0) return fail(ctx, JDSP_EINVAL, "jdsp_mfcc_frames: negative size");
+    if (n_frames == 0) return JDSP_OK;
+    if (!pcm_host || !feats_host) return fail(ctx, JDSP_EINVAL, "jdsp_mfcc_frames: NULL buffer");
+    for (long j = 0; j < n_frames; j++) {          // every frame must lie inside the buffer
+        const long long st = frame_start_host ? frame_start_host[j] : (long long)h->cfg.hop * j;
+        if (st < 0 || st + h->cfg.win_len > n_samples) return fail(ctx, JDSP_EINVAL, "jdsp_mfcc_frames: frame outside pcm");
+    }
+    JDSP_HIP(ctx, hipSetDevice(ctx->device));
+    int16_t *d_in = nullptr;
+    int64_t *d_st = nullptr;
+    double *d_out = nullptr;
+    const size_t out_b = (size_t)n_frames * h->cfg.n_cep * sizeof(double);
+    hipError_t e = hipMalloc((void **)&d_in, (size_t)n_samples * 2);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_out, out_b);
+    if (e == hipSuccess && frame_start_host) e = hipMalloc((void **)&d_st, (size_t)n_frames * 8);
+    int rc = JDSP_OK;
+    if (e != hipSuccess) rc = fail(ctx, JDSP_ENOMEM, "jdsp_mfcc_frames: hipMalloc", e);
+    if (!rc && (e = hipMemcpyAsync(d_in, pcm_host, (size_t)n_samples * 2, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess)
+        rc = fail(ctx, JDSP_EHIP, "jdsp_mfcc_frames: H2D", e);
+    if (!rc && frame_start_host &&
+        (e = hipMemcpyAsync(d_st, frame_start_host, (size_t)n_frames * 8, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess)
+        rc = fail(ctx, JDSP_EHIP, "jdsp_mfcc_frames: H2D", e);
+    if (!rc) rc = jdsp_mfcc_frames_dev(h, d_in, d_st, n_frames, d_out);
+    if (!rc && (e = hipMemcpyAsync(feats_host, d_out, out_b, hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess)
+        rc = fail(ctx, JDSP_EHIP, "jdsp_mfcc_frames: D2H", e);
+    if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess && !rc) rc = fail(ctx, JDSP_EHIP, "jdsp_mfcc_frames: sync", e);
+    if (d_in) (void)hipFree(d_in);
+    if (d_st) (void)hipFree(d_st);
+    if (d_out) (void)hipFree(d_out);
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,94 @@
+// mfcc_kernels.hip -- MFCCFeatureExtraction_auto_version1.cpp:194-231 on gfx950, one frame
+// per wavefront: pre-emphasis (:208-210) -> Hamming (:212-214) -> 1024-point forward transform
+// (:216-217) -> |X| (:218-220) -> mel filterbank + ln (:154-174) -> DCT-II (:176-183) ->
+// sinusoidal lifter (:185-192), n_cep doubles out per frame.
+//
+// n_fft = 512 (BASELINE config 4: 400-sample window, 512-FFT) runs on the same 1024-point
+// machinery: the 512-point spectrum of a frame is exactly the even bins of the 1024-point
+// spectrum of the same frame zero-padded.
+#include "frame_io.h"
+#include "jdsp_internal.h"
+
+namespace jdsp {
+
+__global__ __launch_bounds__(64) void mfcc_kernel(const short *__restrict__ pcm, const long long *__restrict__ starts,
+                                                  long n_frames, MfccDev p, const float2 *__restrict__ table,
+                                                  double *__restrict__ feats)
+{
+    __shared__ __attribute__((aligned(16))) float2 lds[kWaveLdsComplex];
+    __shared__ float mag[512];
+    __shared__ float logmel[64];
+    const int lane = threadIdx.x;
+    const long per_xcd = (gridDim.x + 7) >> 3;
+    const long f = (long)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (f >= n_frames) return;
+    const short *src = pcm + (starts ? starts[f] : (long long)p.hop * f);
+
+    WaveTwiddles tw;
+    load_wave_twiddles(tw, table, lane);
+    const float2 wsp0 = table[kStftSplit + 2 * lane];
+    const float2 wsp1 = table[kStftSplit + 2 * lane + 1];
+
+    // x[i] = s[i] - preemph * s[i-1] for 1 <= i < win_len, x[0] = 0 (:208 starts at i = 1), zero beyond
+    float2 v[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const int i0 = 2 * lane + 128 * r;
+        float sm = 0.f, s0 = 0.f, s1 = 0.f;
+        if (i0 >= 1 && i0 - 1 < p.win_len) sm = (float)src[i0 - 1];
+        if (i0 < p.win_len) s0 = (float)src[i0];
+        if (i0 + 1 < p.win_len) s1 = (float)src[i0 + 1];
+        const float2 w = p.window[lane + 64 * r];            // halved Hamming pair, zero beyond win_len
+        float x0 = (i0 >= 1) ? s0 - p.preemph * sm : 0.f;
+        float x1 = s1 - p.preemph * s0;
+        v[r] = make_float2(x0 * w.x, x1 * w.y);
+    }
+    wave_fft512<false>(v, lds, lane, tw);
+#pragma unroll
+    for (int d = 0; d < 8; d++) lds[lane + 64 * d] = v[d];
+    wave_lds_fence();
+    // |X[m]| for m = 128 j + 2 lane + e < 512 (:218-220 computes all 1024, only these are used)
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int m = 128 * j + 2 * lane;
+        const float4 zz = *reinterpret_cast<const float4 *>(&lds[m]);
+        const float2 zr0 = lds[(512 - m) & 511];
+        const float2 zr1 = lds[511 - m];
+        float2 lo0, hi0, lo1, hi1;
+        if (j == 0) { split_fwd<0>(make_float2(zz.x, zz.y), zr0, wsp0, lo0, hi0); split_fwd<0>(make_float2(zz.z, zz.w), zr1, wsp1, lo1, hi1); }
+        if (j == 1) { split_fwd<1>(make_float2(zz.x, zz.y), zr0, wsp0, lo0, hi0); split_fwd<1>(make_float2(zz.z, zz.w), zr1, wsp1, lo1, hi1); }
+        if (j == 2) { split_fwd<2>(make_float2(zz.x, zz.y), zr0, wsp0, lo0, hi0); split_fwd<2>(make_float2(zz.z, zz.w), zr1, wsp1, lo1, hi1); }
+        if (j == 3) { split_fwd<3>(make_float2(zz.x, zz.y), zr0, wsp0, lo0, hi0); split_fwd<3>(make_float2(zz.z, zz.w), zr1, wsp1, lo1, hi1); }
+        const float a0 = sqrtf(lo0.x * lo0.x + lo0.y * lo0.y);
+        const float a1 = sqrtf(lo1.x * lo1.x + lo1.y * lo1.y);
+        if (p.bin_stride == 1) *reinterpret_cast<float2 *>(&mag[m]) = make_float2(a0, a1);
+        else mag[m >> 1] = a0;                               // 512-point bins = even 1024-point bins
+    }
+    wave_lds_fence();
+    // mel filterbank: channel c sums bins [start[c], start[c]+len[c]) with the triangular
+    // weights MelFilterBank() applies in the same ascending-bin order (:157-168), then ln (:171)
+    if (lane < p.n_chan) {
+        const int st = p.mel_start[lane], ln = p.mel_len[lane];
+        float acc = 0.f;
+        for (int t = 0; t < ln; t++) acc += p.mel_w[t * 64 + lane] * mag[st + t];
+        logmel[lane] = logf(acc);
+    }
+    wave_lds_fence();
+    // DCT-II (:178-182) and lifter (:189)
+    if (lane < p.n_cep) {
+        double acc = 0.0;
+        for (int k = 0; k < p.n_chan; k++) acc += p.dct[k * 32 + lane] * (double)logmel[k];
+        feats[f * p.n_cep + lane] = acc * p.lifter_w[lane];
+    }
+}
+
+int launch_mfcc(hipStream_t s, const short *pcm, const long long *starts, long n_frames, const MfccDev &p,
+                const float2 *table, double *feats)
+{
+    if (n_frames <= 0) return 0;
+    long grid = (n_frames + 7) / 8 * 8;
+    hipLaunchKernelGGL(mfcc_kernel, dim3((unsigned)grid), dim3(64), 0, s, pcm, starts, n_frames, p, table, feats);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+}  // namespace jdsp

@@ -56,6 +56,9 @@ class Engine:
     def set_option(self, name, value):
         self._ck(L.jdsp_set_option(self._h, name.encode(), int(value)))
 
+    def mfcc(self, **cfg):
+        return Mfcc(self, **cfg)
+
     def denoiser(self, mode):
         return Denoiser(self, mode)
 
@@ -189,3 +192,72 @@ class Denoiser:
         self.eng._ck(L.jdsp_denoise_vad_trace(self._h, n, v.ctypes.data_as(C.c_void_p), e.ctypes.data_as(C.c_void_p),
                                               z.ctypes.data_as(C.c_void_p)))
         return v, e, z
+
+
+class Mfcc:
+    """MFCC front end (jdsp_mfcc): MFCCFeatureExtraction_auto_version1.cpp for batches of frames.
+    Keyword arguments override the reference-native configuration (jdsp_mfcc_native_cfg)."""
+
+    def __init__(self, engine, **kw):
+        self.eng = engine
+        cfg = _lib.MfccCfg()
+        engine._ck(L.jdsp_mfcc_native_cfg(C.byref(cfg)))
+        for k, v in kw.items():
+            setattr(cfg, k, v)
+        self.cfg = cfg
+        h = C.c_void_p()
+        engine._ck(L.jdsp_mfcc_create(engine._h, C.byref(cfg), C.byref(h)))
+        self._h = h
+        engine._children.append(self)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            L.jdsp_mfcc_destroy(self._h)
+            self._h = None
+            if self in self.eng._children:
+                self.eng._children.remove(self)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def tables(self):
+        """MelFilterBankInit's rgdMelFreqs, rgdFiBins, rgdFilterBank."""
+        nb = self.cfg.n_fft // 2
+        mel = np.zeros(self.cfg.n_chan + 1, np.float64)
+        fi = np.zeros(nb, np.int32)
+        fb = np.zeros(nb, np.float64)
+        self.eng._ck(L.jdsp_mfcc_tables(self._h, mel.ctypes.data_as(C.c_void_p), fi.ctypes.data_as(C.c_void_p),
+                                        fb.ctypes.data_as(C.c_void_p)))
+        return mel, fi, fb
+
+    def n_frames(self, n_samples):
+        return (n_samples - self.cfg.win_len) // self.cfg.hop + 1 if n_samples >= self.cfg.win_len else 0
+
+    def frames(self, pcm, n_frames=None, frame_start=None):
+        """Feature vectors [n_frames, n_cep] float64; frame j starts at frame_start[j] (default hop*j)."""
+        if _is_torch(pcm):
+            import torch
+            assert pcm.is_cuda and pcm.dtype == torch.int16 and pcm.is_contiguous()
+            if n_frames is None:
+                n_frames = len(frame_start) if frame_start is not None else self.n_frames(pcm.numel())
+            out = torch.empty((n_frames, self.cfg.n_cep), dtype=torch.float64, device=pcm.device)
+            if frame_start is not None:
+                assert frame_start.is_cuda and frame_start.dtype == torch.int64 and frame_start.numel() >= n_frames
+            self.eng._use_torch_stream()
+            self.eng._ck(L.jdsp_mfcc_frames_dev(self._h, C.c_void_p(pcm.data_ptr()),
+                                                C.c_void_p(frame_start.data_ptr()) if frame_start is not None else None,
+                                                n_frames, C.c_void_p(out.data_ptr())))
+            return out
+        pcm = np.ascontiguousarray(pcm, np.int16)
+        if frame_start is not None:
+            frame_start = np.ascontiguousarray(frame_start, np.int64)
+        if n_frames is None:
+            n_frames = len(frame_start) if frame_start is not None else self.n_frames(pcm.size)
+        out = np.zeros((n_frames, self.cfg.n_cep), np.float64)
+        self.eng._ck(L.jdsp_mfcc_frames(self._h, pcm.ctypes.data_as(C.c_void_p), pcm.size,
+                                        frame_start.ctypes.data_as(C.c_void_p) if frame_start is not None else None,
+                                        n_frames, out.ctypes.data_as(C.c_void_p)))
+        return out
