@@ -134,6 +134,30 @@ int jdsp_denoise_noise(jdsp_denoise *h, double *noise_host);
 int jdsp_denoise_vad_trace(jdsp_denoise *h, long n, uint8_t *voice_host, int64_t *energy_sum_host,
                            int32_t *zcr_host);
 
+/* ---- overlap-save fast convolution --------------------------------------------- */
+/* Fast_Convolution_Based_3DAudio_Impl.cpp.  jdsp_fastconv_create replaces main()'s filter
+ * set-up (:82-84) and the per-block FFT of the filter (:140,:143): taps is n_filters rows of
+ * n_taps doubles (the reference: one row, rgdFirLPF_coefficients[7169] of FilterCoefficient.h);
+ * n_fft is 8192 (reference-native) or 1024; block = n_fft - n_taps + 1 samples per call
+ * (1024 native).  jdsp_fastconv_process* replaces AnalySisFreqDomain (:102-177) for n_blocks
+ * blocks: like the reference, the first hist_blocks = ceil((n_taps-1)/block) blocks of a
+ * stream produce no output (:119-123) and never reach the transform (the reference queues
+ * uninitialised buffers for them, :120 -- defined as silence here).  out: n_filters planes of
+ * n_out*block int16, plane-major; precast (may be NULL): the same values before the (short)
+ * cast.  The handle carries the last n_taps-1 samples between calls. */
+typedef struct jdsp_fastconv jdsp_fastconv;
+int jdsp_fastconv_create(jdsp_ctx *ctx, const double *taps, int n_taps, int n_filters, int n_fft,
+                         jdsp_fastconv **out);
+int jdsp_fastconv_destroy(jdsp_fastconv *h);
+int jdsp_fastconv_reset(jdsp_fastconv *h);
+int jdsp_fastconv_block_len(const jdsp_fastconv *h);
+int jdsp_fastconv_hist_blocks(const jdsp_fastconv *h);
+long jdsp_fastconv_blocks_out(const jdsp_fastconv *h, long n_blocks);
+int jdsp_fastconv_process_dev(jdsp_fastconv *h, const int16_t *pcm_dev, long n_blocks, int16_t *out_dev,
+                              float *precast_dev, long *n_out_blocks);
+int jdsp_fastconv_process(jdsp_fastconv *h, const int16_t *pcm_host, long n_blocks, int16_t *out_host,
+                          float *precast_host, long *n_out_blocks);
+
 /* ---- MFCC ---------------------------------------------------------------------- */
 /* MFCCFeatureExtraction_auto_version1.cpp.  The #defines at :23-33 become a runtime
  * configuration; jdsp_mfcc_native_cfg() fills in the reference's values

@@ -72,6 +72,14 @@ def _load():
         "jdsp_mfcc_tables": (i, [vp, vp, vp, vp]),
         "jdsp_mfcc_frames_dev": (i, [vp, vp, vp, l, vp]),
         "jdsp_mfcc_frames": (i, [vp, vp, l, vp, l, vp]),
+        "jdsp_fastconv_create": (i, [vp, vp, i, i, i, C.POINTER(vp)]),
+        "jdsp_fastconv_destroy": (i, [vp]),
+        "jdsp_fastconv_reset": (i, [vp]),
+        "jdsp_fastconv_block_len": (i, [vp]),
+        "jdsp_fastconv_hist_blocks": (i, [vp]),
+        "jdsp_fastconv_blocks_out": (l, [vp, l]),
+        "jdsp_fastconv_process_dev": (i, [vp, vp, l, vp, vp, C.POINTER(l)]),
+        "jdsp_fastconv_process": (i, [vp, vp, l, vp, vp, C.POINTER(l)]),
         "jdsp_stft_i16_dev": (i, [vp, vp, l, i, i, vp]),
         "jdsp_stft_i16": (i, [vp, vp, l, i, i, vp, C.POINTER(l)]),
     }

@@ -78,6 +78,8 @@ int jdsp_destroy(jdsp_ctx *ctx)
     if (ctx->stft1024_table) (void)hipFree(ctx->stft1024_table);
     for (auto &p : ctx->c2c_tw)
         if (p) (void)hipFree(p);
+    if (ctx->conv_tw4096) (void)hipFree(ctx->conv_tw4096);
+    if (ctx->conv_tw8192) (void)hipFree(ctx->conv_tw8192);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
     return JDSP_OK;

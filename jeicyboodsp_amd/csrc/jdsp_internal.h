@@ -23,6 +23,7 @@ struct jdsp_ctx {
     // device tables, created on first use
     float2 *stft1024_table = nullptr;
     double2 *c2c_tw[16] = {nullptr};   // by log2(n_fft)
+    float2 *conv_tw4096 = nullptr, *conv_tw8192 = nullptr;
 };
 
 namespace jdsp {
@@ -83,6 +84,24 @@ int launch_denoise(hipStream_t s, int mode, int k_opt, const short *pcm, long n_
                    const DenoiseState *st_in, DenoiseState *st_out, const int *ver, const float *noise_rows,
                    const float2 *table, short *out, float *precast);
 int ensure_stft1024_table(jdsp_ctx *ctx);
+// fastconv_kernels.hip
+// (fastconv) Sample `pos` of this call's stream (pos < 0: history carried in the handle).  Samples of
+// the first n_hist blocks of a stream never reach the transform in the reference (its queue
+// holds uninitialised malloc() blocks for them, :120): they are defined as zero.
+struct ConvStream {
+    const short *pcm;        // this call's samples
+    const short *hist;       // last hist_len samples before this call
+    long n_samples;          // in pcm
+    long global0;            // global index of pcm[0]
+    long valid_from;         // global index of the first sample that exists for the convolver
+    int hist_len;
+};
+
+int launch_spectrum_to_f32(hipStream_t s, const double2 *in, float2 *out, long n);
+int launch_fastconv(hipStream_t st, int n_fft, const ConvStream &s, long n_out_blocks, int first_block, int block,
+                    int n_taps, int n_filters, const float2 *H, const float2 *table, const float2 *tw4096,
+                    const float2 *tw8192, short *out, float *precast, long plane, short *hist_out);
+void fill_conv_twiddles(float2 *tw4096, float2 *tw8192);
 // mfcc_kernels.hip
 int launch_mfcc(hipStream_t s, const short *pcm, const long long *starts, long n_frames, const MfccDev &p,
                 const float2 *table, double *feats);
@@ -114,4 +133,13 @@ struct jdsp_mfcc {
     void *blob = nullptr;                 // one device allocation holding every table
     std::vector<double> mel_freqs, fbank;
     std::vector<int> fi_bins;
+};
+
+struct jdsp_fastconv {
+    jdsp_ctx *ctx = nullptr;
+    int n_fft = 0, n_taps = 0, n_filters = 0, block = 0, n_hist = 0;
+    float2 *H = nullptr;                  // [n_filters][n_fft]
+    short *hist[2] = {nullptr, nullptr};  // last n_taps-1 samples of the stream, ping-pong
+    int cur = 0;
+    long calls = 0;                       // blocks consumed so far (siNumOfCount)
 };

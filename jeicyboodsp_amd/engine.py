@@ -56,6 +56,9 @@ class Engine:
     def set_option(self, name, value):
         self._ck(L.jdsp_set_option(self._h, name.encode(), int(value)))
 
+    def fastconv(self, taps, n_fft):
+        return FastConv(self, taps, n_fft)
+
     def mfcc(self, **cfg):
         return Mfcc(self, **cfg)
 
@@ -261,3 +264,68 @@ class Mfcc:
                                         frame_start.ctypes.data_as(C.c_void_p) if frame_start is not None else None,
                                         n_frames, out.ctypes.data_as(C.c_void_p)))
         return out
+
+
+class FastConv:
+    """Overlap-save convolver (jdsp_fastconv): AnalySisFreqDomain of
+    Fast_Convolution_Based_3DAudio_Impl.cpp:102-177 for batches of blocks.
+    taps: [n_taps] or [n_filters, n_taps] float64."""
+
+    def __init__(self, engine, taps, n_fft):
+        self.eng = engine
+        taps = np.ascontiguousarray(np.atleast_2d(np.asarray(taps, np.float64)))
+        self.n_filters, self.n_taps = taps.shape
+        h = C.c_void_p()
+        engine._ck(L.jdsp_fastconv_create(engine._h, taps.ctypes.data_as(C.c_void_p), self.n_taps, self.n_filters,
+                                          int(n_fft), C.byref(h)))
+        self._h = h
+        self.block = L.jdsp_fastconv_block_len(h)
+        self.hist_blocks = L.jdsp_fastconv_hist_blocks(h)
+        engine._children.append(self)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            L.jdsp_fastconv_destroy(self._h)
+            self._h = None
+            if self in self.eng._children:
+                self.eng._children.remove(self)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def reset(self):
+        self.eng._ck(L.jdsp_fastconv_reset(self._h))
+
+    def blocks_out(self, n_blocks):
+        return L.jdsp_fastconv_blocks_out(self._h, n_blocks)
+
+    def process(self, pcm, want_precast=False):
+        """pcm: int16, whole blocks of self.block samples.  Returns out [n_filters, n_out*block] (and precast)."""
+        if _is_torch(pcm):
+            import torch
+            assert pcm.is_cuda and pcm.dtype == torch.int16 and pcm.is_contiguous() and pcm.numel() % self.block == 0
+            nb = pcm.numel() // self.block
+            n_out = self.blocks_out(nb)
+            shape = (self.n_filters, max(n_out, 1) * self.block)
+            out = torch.empty(shape, dtype=torch.int16, device=pcm.device)
+            pre = torch.empty(shape, dtype=torch.float32, device=pcm.device) if want_precast else None
+            if n_out == 0:
+                out, pre = out[:, :0], (pre[:, :0] if want_precast else None)
+            self.eng._use_torch_stream()
+            self.eng._ck(L.jdsp_fastconv_process_dev(self._h, C.c_void_p(pcm.data_ptr()), nb, C.c_void_p(out.data_ptr()),
+                                                     C.c_void_p(pre.data_ptr()) if want_precast else None, None))
+            return (out, pre) if want_precast else out
+        pcm = np.ascontiguousarray(pcm, np.int16)
+        assert pcm.size % self.block == 0
+        nb = pcm.size // self.block
+        n_out = self.blocks_out(nb)
+        out = np.zeros((self.n_filters, n_out * self.block), np.int16)
+        pre = np.zeros((self.n_filters, n_out * self.block), np.float32) if want_precast else None
+        dummy = np.zeros(1, np.int16)
+        self.eng._ck(L.jdsp_fastconv_process(self._h, pcm.ctypes.data_as(C.c_void_p), nb,
+                                             (out if out.size else dummy).ctypes.data_as(C.c_void_p),
+                                             pre.ctypes.data_as(C.c_void_p) if (want_precast and pre.size) else None, None))
+        return (out, pre) if want_precast else out
