@@ -134,6 +134,18 @@ int jdsp_denoise_noise(jdsp_denoise *h, double *noise_host);
 int jdsp_denoise_vad_trace(jdsp_denoise *h, long n, uint8_t *voice_host, int64_t *energy_sum_host,
                            int32_t *zcr_host);
 
+/* The reference's two helper functions on their own, for callers that keep main()'s
+ * structure (jeicyboodsp_amd/compat): */
+/* VoiceActivityDetection (SS:121-156) for n_blocks blocks of 512 host samples; outputs as
+ * jdsp_denoise_vad_trace.  Any output pointer may be NULL. */
+int jdsp_vad_blocks(jdsp_ctx *ctx, const int16_t *pcm_host, long n_blocks, uint8_t *voice_host,
+                    int64_t *energy_sum_host, int32_t *zcr_host);
+/* SpectralSubtraction / WienerFiltering (SS:201-264 / WF:162-235) with the CALLER's
+ * pdEstimatedNoiseSpec (1024 doubles, host) instead of the handle's own VAD + estimate: only
+ * the keep buffer, the overlap buffer and the call counter of the handle are used. */
+int jdsp_denoise_apply(jdsp_denoise *h, const int16_t *pcm_host, long n_blocks, const double *noise_host,
+                       int16_t *out_host, float *precast_host, long *n_out_blocks);
+
 /* ---- overlap-save fast convolution --------------------------------------------- */
 /* Fast_Convolution_Based_3DAudio_Impl.cpp.  jdsp_fastconv_create replaces main()'s filter
  * set-up (:82-84) and the per-block FFT of the filter (:140,:143): taps is n_filters rows of

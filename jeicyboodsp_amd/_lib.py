@@ -80,6 +80,8 @@ def _load():
         "jdsp_fastconv_blocks_out": (l, [vp, l]),
         "jdsp_fastconv_process_dev": (i, [vp, vp, l, vp, vp, C.POINTER(l)]),
         "jdsp_fastconv_process": (i, [vp, vp, l, vp, vp, C.POINTER(l)]),
+        "jdsp_vad_blocks": (i, [vp, vp, l, vp, vp, vp]),
+        "jdsp_denoise_apply": (i, [vp, vp, l, vp, vp, vp, C.POINTER(l)]),
         "jdsp_stft_i16_dev": (i, [vp, vp, l, i, i, vp]),
         "jdsp_stft_i16": (i, [vp, vp, l, i, i, vp, C.POINTER(l)]),
     }

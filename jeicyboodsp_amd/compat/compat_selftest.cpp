@@ -1,0 +1,73 @@
+// compat_selftest.cpp -- drives the reference-signature functions exactly the way the
+// reference main()s do (one block per call) and dumps what they return, for tests/ to compare
+// with the oracle.  usage: compat_selftest <ss|wf|conv|mfcc|fft> in.raw out.bin [taps.f64]
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "jeicyboo_compat.h"
+
+static std::vector<short> slurp(const char *p)
+{
+    FILE *f = fopen(p, "rb");
+    if (!f) { perror(p); exit(1); }
+    std::vector<short> v;
+    short s;
+    while (fread(&s, 2, 1, f) == 1) v.push_back(s);
+    fclose(f);
+    return v;
+}
+
+int main(int argc, char **argv)
+{
+    if (argc < 4) return 1;
+    const char *what = argv[1];
+    std::vector<short> pcm = slurp(argv[2]);
+    FILE *out = fopen(argv[3], "wb");
+    if (!strcmp(what, "ss") || !strcmp(what, "wf")) {
+        // SpectralSubtraction_final.cpp:92-113 verbatim in structure
+        short temp[512] = {0}, ob[512] = {0};
+        double noise[1024] = {0};
+        int iter = 0;
+        for (size_t b = 0; b + 512 <= pcm.size(); b += 512) {
+            short *in = &pcm[b];
+            if (!VoiceActivityDetection(in, 512)) {
+                iter++;
+                if (iter == 1) memcpy(temp, in, sizeof(temp));
+                else if (iter > 1) EstimateNoiseSpectrum(temp, iter, in, noise, 512);
+            } else iter = 0;
+            bool ok = !strcmp(what, "ss") ? SpectralSubtraction(in, noise, ob, 512) : WienerFiltering(in, noise, ob, 512);
+            if (ok) fwrite(ob, 2, 512, out);
+        }
+    } else if (!strcmp(what, "conv")) {
+        static double filt[8192][2];
+        FILE *tf = fopen(argv[4], "rb");
+        double v; int i = 0;
+        while (fread(&v, 8, 1, tf) == 1 && i < 8192) filt[i++][0] = v;
+        fclose(tf);
+        short ob[1024];
+        for (size_t b = 0; b + 1024 <= pcm.size(); b += 1024)
+            if (AnalySisFreqDomain(&pcm[b], ob, 1024, filt)) fwrite(ob, 2, 1024, out);
+    } else if (!strcmp(what, "mfcc")) {
+        double feat[2][12];
+        int it = 0;
+        MelFilterBankInit();
+        for (size_t b = 0; b + 1024 <= pcm.size(); b += 1024, it++)
+            if (MFCCFeatureExtraction(&pcm[b], feat))
+                for (int i = 0; i < 2; i++)
+                    if (!(it == 0 && i == 0)) fwrite(feat[i], 8, 12, out);          // MFCC:94-101
+    } else if (!strcmp(what, "fft")) {
+        std::vector<COMPLEX> a(512), b(512);
+        short bits[512];
+        for (size_t blk = 0; blk + 512 <= pcm.size(); blk += 512) {
+            for (int i = 0; i < 512; i++) { a[i].real = pcm[blk + i]; a[i].imag = 0; }
+            FFTProcess(a.data(), b.data(), 512, true);
+            fwrite(b.data(), sizeof(COMPLEX), 512, out);
+        }
+        Bitrev(a.data(), bits, 512, b.data());
+        fwrite(bits, 2, 512, out);
+    }
+    fclose(out);
+    return 0;
+}

@@ -1,0 +1,186 @@
+// jeicyboo_compat.cpp -- see jeicyboo_compat.h.
+#include "jeicyboo_compat.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+namespace {
+
+int g_block_len = 512;
+int g_device = -1;
+jdsp_ctx *g_ctx = nullptr;
+jdsp_denoise *g_dn[2] = {nullptr, nullptr};
+jdsp_fastconv *g_conv = nullptr;
+jdsp_mfcc *g_mfcc = nullptr;
+
+// EstimateNoiseSpectrum's statics (SS:161,164)
+double g_avg[1024];
+short g_est_keep[512];
+// MFCCFeatureExtraction's static (MFCC:198)
+short g_mfcc_keep[512];
+
+[[noreturn]] void die(const char *what, jdsp_ctx *ctx)
+{
+    fprintf(stderr, "jeicyboo_compat: %s: %s\n", what, jdsp_last_error(ctx));
+    abort();
+}
+
+#define CK(call)                                  \
+    do {                                          \
+        if ((call) != JDSP_OK) die(#call, g_ctx); \
+    } while (0)
+
+}  // namespace
+
+double rgdFilterBank[512] = {0};
+int rgdFiBins[512] = {0};
+double rgdMelFreqs[39] = {0};
+
+void JeicybooSetBlockLen(int block_len) { g_block_len = block_len; }
+void JeicybooSetDevice(int d) { g_device = d; }
+
+jdsp_ctx *JeicybooContext(void)
+{
+    if (!g_ctx) {
+        int dev = g_device;
+        if (dev < 0) {
+            const char *e = getenv("JDSP_DEVICE");
+            dev = e ? atoi(e) : 0;
+        }
+        if (jdsp_create(dev, &g_ctx) != JDSP_OK) die("jdsp_create", nullptr);
+    }
+    return g_ctx;
+}
+
+void JeicybooResetStreams(void)
+{
+    for (auto &h : g_dn) { if (h) jdsp_denoise_destroy(h); h = nullptr; }
+    if (g_conv) jdsp_fastconv_destroy(g_conv);
+    g_conv = nullptr;
+    if (g_mfcc) jdsp_mfcc_destroy(g_mfcc);
+    g_mfcc = nullptr;
+    memset(g_avg, 0, sizeof(g_avg));
+    memset(g_est_keep, 0, sizeof(g_est_keep));
+    memset(g_mfcc_keep, 0, sizeof(g_mfcc_keep));
+}
+
+// ---- FFTAlgorithm_ver2.cpp ----------------------------------------------------------------
+void FFTProcess(COMPLEX *in, COMPLEX *out, int n, bool dir)
+{
+    CK(jdsp_fft_process_f64(JeicybooContext(), (const double *)in, (double *)out, n, 1, dir ? 1 : 0));
+}
+
+void Bitrev(COMPLEX *in, short *bits, int n, COMPLEX *out)
+{
+    CK(jdsp_bitrev_table(JeicybooContext(), n, g_block_len, bits));
+    for (int k = 0; k < n; k++) out[k] = in[bits[k]];                    // :204-205
+}
+
+void DFTProcess(short *in, COMPLEX *out, int n)
+{
+    std::vector<COMPLEX> a(n), b(n);
+    for (int i = 0; i < n; i++) { a[i].real = in[i]; a[i].imag = 0; }
+    FFTProcess(a.data(), b.data(), n, true);
+    for (int i = 0; i < n; i++) { out[i].real += b[i].real; out[i].imag += b[i].imag; }   // the reference accumulates (:168)
+}
+
+void IDFTProcess(COMPLEX *in, COMPLEX *out, int n)
+{
+    std::vector<COMPLEX> b(n);
+    FFTProcess(in, b.data(), n, false);
+    for (int i = 0; i < n; i++) { out[i].real += b[i].real; out[i].imag += b[i].imag; }   // :178
+}
+
+void IFFTProcess(COMPLEX *in, COMPLEX *out, int n)
+{
+    std::vector<COMPLEX> b(n);
+    FFTProcess(in, b.data(), n, false);
+    for (int i = 0; i < n; i++) { out[i].real += b[i].real / n; out[i].imag += b[i].imag / n; }   // :154
+}
+
+// ---- SpectralSubtraction_final.cpp / WienerFilter_final.cpp --------------------------------
+bool VoiceActivityDetection(short *block, int n)
+{
+    if (n != 512) { fprintf(stderr, "VoiceActivityDetection: iFrameCount must be 512\n"); abort(); }
+    uint8_t v = 0;
+    CK(jdsp_vad_blocks(JeicybooContext(), block, 1, &v, nullptr, nullptr));
+    return v != 0;
+}
+
+void EstimateNoiseSpectrum(short *temp, int iter, short *in, double *noise, int n)
+{
+    if (n != 512) { fprintf(stderr, "EstimateNoiseSpectrum: iFrameCount must be 512\n"); abort(); }
+    if (iter == 2) memcpy(g_est_keep, temp, sizeof(g_est_keep));                         // SS:165-167
+    short frame[1024];
+    memcpy(frame, g_est_keep, sizeof(g_est_keep));
+    memcpy(frame + 512, in, sizeof(short) * 512);
+    static jdsp_c32 spec[1024];
+    long nf = 0;
+    CK(jdsp_stft_i16(JeicybooContext(), frame, 1024, 1024, 512, spec, &nf));             // SS:168-180 on the GPU
+    for (int i = 0; i < 1024; i++) {                                                      // SS:182-187
+        g_avg[i] += sqrt((double)spec[i].re * spec[i].re + (double)spec[i].im * spec[i].im);
+        if (iter >= 3) g_avg[i] /= 2.0;
+    }
+    if (iter == 10) memcpy(noise, g_avg, sizeof(g_avg));                                  // SS:189-193
+    memcpy(g_est_keep, in, sizeof(g_est_keep));                                           // SS:195
+}
+
+static bool denoise_one(int mode, short *in, double *noise, short *out, int n)
+{
+    if (n != 512) { fprintf(stderr, "SpectralSubtraction/WienerFiltering: iFrameCount must be 512\n"); abort(); }
+    jdsp_ctx *ctx = JeicybooContext();
+    if (!g_dn[mode]) CK(jdsp_denoise_create(ctx, mode, &g_dn[mode]));
+    long n_out = 0;
+    short tmp[512];
+    CK(jdsp_denoise_apply(g_dn[mode], in, 1, noise, tmp, nullptr, &n_out));
+    if (n_out == 1) memcpy(out, tmp, sizeof(tmp));
+    return n_out == 1;                                                                    // SS:260-263
+}
+
+bool SpectralSubtraction(short *in, double *noise, short *out, int n) { return denoise_one(JDSP_SPECSUB, in, noise, out, n); }
+bool WienerFiltering(short *in, double *noise, short *out, int n) { return denoise_one(JDSP_WIENER, in, noise, out, n); }
+
+// ---- Fast_Convolution_Based_3DAudio_Impl.cpp ------------------------------------------------
+bool AnalySisFreqDomain(short *in, short *out, int n, double (*filter)[2])
+{
+    jdsp_ctx *ctx = JeicybooContext();
+    if (!g_conv) {
+        const int n_fft = 8192;                                   // FFT_PROCESSING_SIZE (:48)
+        const int n_taps = n_fft - n + 1;                         // FILTER_LENGTH 7169 for BLOCK_SIZE 1024
+        std::vector<double> taps(n_taps);
+        for (int i = 0; i < n_taps; i++) taps[i] = filter[i][0];  // :82-84
+        CK(jdsp_fastconv_create(ctx, taps.data(), n_taps, 1, n_fft, &g_conv));
+    }
+    if (n != jdsp_fastconv_block_len(g_conv)) { fprintf(stderr, "AnalySisFreqDomain: iFrameCount changed\n"); abort(); }
+    long n_out = 0;
+    std::vector<short> tmp(n);
+    CK(jdsp_fastconv_process(g_conv, in, 1, tmp.data(), nullptr, &n_out));
+    if (n_out == 1) memcpy(out, tmp.data(), sizeof(short) * n);
+    return n_out == 1;                                            // :122,:176
+}
+
+// ---- MFCCFeatureExtraction_auto_version1.cpp ------------------------------------------------
+void MelFilterBankInit()
+{
+    jdsp_ctx *ctx = JeicybooContext();
+    if (!g_mfcc) {
+        jdsp_mfcc_cfg cfg;
+        jdsp_mfcc_native_cfg(&cfg);
+        CK(jdsp_mfcc_create(ctx, &cfg, &g_mfcc));
+    }
+    CK(jdsp_mfcc_tables(g_mfcc, rgdMelFreqs, rgdFiBins, rgdFilterBank));
+}
+
+bool MFCCFeatureExtraction(short *in, double (*feat)[12])
+{
+    if (!g_mfcc) MelFilterBankInit();
+    short buf[512 + 1024];                                        // rgsProcessingBuffer (:199,:203-204)
+    memcpy(buf, g_mfcc_keep, sizeof(g_mfcc_keep));
+    memcpy(buf + 512, in, sizeof(short) * 1024);
+    CK(jdsp_mfcc_frames(g_mfcc, buf, 1536, nullptr, 2, &feat[0][0]));   // frames at offsets 0 and 512 (:205)
+    memcpy(g_mfcc_keep, in + 512, sizeof(g_mfcc_keep));           // :228
+    return true;
+}

@@ -33,12 +33,8 @@ int jdsp_denoise_create(jdsp_ctx *ctx, int mode, jdsp_denoise **out)
     hipError_t e = hipSuccess;
     for (int i = 0; i < 2 && e == hipSuccess; i++) e = hipMalloc((void **)&h->st[i], sizeof(jdsp::DenoiseState));
     if (e == hipSuccess) e = hipMalloc((void **)&h->plan, sizeof(jdsp::DenoisePlan));
-    if (e == hipSuccess) e = hipMalloc((void **)&h->w_hi, sizeof(double) * 512);
-    if (e == hipSuccess) {
-        double w[512];
-        for (int i = 0; i < 512; i++) w[i] = (0.54 - 0.46 * cos(2 * 3.141592 * (512 + i) / (1024 - 1)));   // SS:131
-        e = hipMemcpy(h->w_hi, w, sizeof(w), hipMemcpyHostToDevice);
-    }
+    if (e == hipSuccess && jdsp::ensure_vad_window(ctx)) e = hipErrorUnknown;
+    h->w_hi = ctx->vad_w_hi;
     if (e != hipSuccess) {
         jdsp_denoise_destroy(h);
         return fail(ctx, JDSP_EHIP, "jdsp_denoise_create: alloc", e);
@@ -61,7 +57,6 @@ int jdsp_denoise_destroy(jdsp_denoise *h)
     for (int i = 0; i < 2; i++)
         if (h->st[i]) (void)hipFree(h->st[i]);
     if (h->plan) (void)hipFree(h->plan);
-    if (h->w_hi) (void)hipFree(h->w_hi);
     delete h;
     return JDSP_OK;
 }
@@ -184,6 +179,87 @@ int jdsp_denoise_process(jdsp_denoise *h, const int16_t *pcm_host, long n_blocks
     if (d_in) (void)hipFree(d_in);
     if (d_out) (void)hipFree(d_out);
     if (d_pre) (void)hipFree(d_pre);
+    return rc;
+}
+
+int jdsp_denoise_apply(jdsp_denoise *h, const int16_t *pcm_host, long n_blocks, const double *noise_host,
+                       int16_t *out_host, float *precast_host, long *n_out_blocks)
+{
+    if (!h) return JDSP_EINVAL;
+    jdsp_ctx *ctx = h->ctx;
+    if (n_blocks < 0 || !noise_host) return fail(ctx, JDSP_EINVAL, "jdsp_denoise_apply: bad argument");
+    const long n_out = jdsp_denoise_blocks_out(h, n_blocks);
+    if (n_out_blocks) *n_out_blocks = n_out;
+    if (n_blocks == 0) return JDSP_OK;
+    if (!pcm_host || (n_out > 0 && !out_host)) return fail(ctx, JDSP_EINVAL, "jdsp_denoise_apply: NULL buffer");
+    JDSP_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = jdsp_denoise_reserve(h, n_blocks);
+    if (rc) return rc;
+    float row[1024];
+    for (int i = 0; i < 1024; i++) row[i] = (float)noise_host[i];
+    const size_t in_b = (size_t)n_blocks * 1024, out_b = (size_t)(n_out > 0 ? n_out : 1) * 1024;
+    int16_t *d_in = nullptr, *d_out = nullptr;
+    float *d_pre = nullptr;
+    hipError_t e = hipMalloc((void **)&d_in, in_b);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_out, out_b);
+    if (e == hipSuccess && precast_host) e = hipMalloc((void **)&d_pre, out_b * 2);
+    hipStream_t s = ctx->stream;
+    jdsp::DenoiseState *st_in = h->st[h->cur], *st_out = h->st[h->cur ^ 1];
+    if (e == hipSuccess) e = hipMemcpyAsync(d_in, pcm_host, in_b, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(h->rows, row, sizeof(row), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemsetAsync(h->ver, 0, (size_t)n_blocks * sizeof(int), s);      // every block uses row 0
+    if (e == hipSuccess) e = hipMemcpyAsync(st_out, st_in, sizeof(jdsp::DenoiseState), hipMemcpyDeviceToDevice, s);
+    if (e != hipSuccess) rc = fail(ctx, JDSP_EHIP, "jdsp_denoise_apply: staging", e);
+    if (!rc && jdsp::launch_denoise(s, h->mode, h->opt_k, d_in, n_blocks, h->calls, st_in, st_out, h->ver, h->rows,
+                                    ctx->stft1024_table, d_out, d_pre))
+        rc = fail(ctx, JDSP_EHIP, "denoise launch", hipGetLastError());
+    if (!rc && n_out > 0 && (e = hipMemcpyAsync(out_host, d_out, (size_t)n_out * 1024, hipMemcpyDeviceToHost, s)) != hipSuccess)
+        rc = fail(ctx, JDSP_EHIP, "jdsp_denoise_apply: D2H", e);
+    if (!rc && n_out > 0 && precast_host &&
+        (e = hipMemcpyAsync(precast_host, d_pre, (size_t)n_out * 2048, hipMemcpyDeviceToHost, s)) != hipSuccess)
+        rc = fail(ctx, JDSP_EHIP, "jdsp_denoise_apply: D2H", e);
+    if ((e = hipStreamSynchronize(s)) != hipSuccess && !rc) rc = fail(ctx, JDSP_EHIP, "jdsp_denoise_apply: sync", e);
+    if (d_in) (void)hipFree(d_in);
+    if (d_out) (void)hipFree(d_out);
+    if (d_pre) (void)hipFree(d_pre);
+    if (!rc) {
+        h->cur ^= 1;
+        h->calls += n_blocks;
+        h->last_blocks = 0;
+    }
+    return rc;
+}
+
+int jdsp_vad_blocks(jdsp_ctx *ctx, const int16_t *pcm_host, long n_blocks, uint8_t *voice_host,
+                    int64_t *energy_sum_host, int32_t *zcr_host)
+{
+    if (!ctx) return JDSP_EINVAL;
+    if (n_blocks < 0 || (n_blocks > 0 && !pcm_host)) return fail(ctx, JDSP_EINVAL, "jdsp_vad_blocks: bad argument");
+    if (n_blocks == 0) return JDSP_OK;
+    JDSP_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = jdsp::ensure_vad_window(ctx);
+    if (rc) return rc;
+    const size_t n = (size_t)n_blocks;
+    int16_t *d_in = nullptr;
+    unsigned char *d_v = nullptr;
+    long long *d_e = nullptr;
+    int *d_z = nullptr;
+    hipError_t e = hipMalloc((void **)&d_in, n * 1024);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_v, n);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_e, n * 8);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_z, n * 4);
+    hipStream_t s = ctx->stream;
+    if (e == hipSuccess) e = hipMemcpyAsync(d_in, pcm_host, n * 1024, hipMemcpyHostToDevice, s);
+    if (e != hipSuccess) rc = fail(ctx, JDSP_EHIP, "jdsp_vad_blocks: staging", e);
+    if (!rc && jdsp::launch_vad(s, d_in, n_blocks, ctx->vad_w_hi, d_v, d_e, d_z)) rc = fail(ctx, JDSP_EHIP, "vad launch", hipGetLastError());
+    if (!rc && voice_host && (e = hipMemcpyAsync(voice_host, d_v, n, hipMemcpyDeviceToHost, s)) != hipSuccess) rc = fail(ctx, JDSP_EHIP, "jdsp_vad_blocks: D2H", e);
+    if (!rc && energy_sum_host && (e = hipMemcpyAsync(energy_sum_host, d_e, n * 8, hipMemcpyDeviceToHost, s)) != hipSuccess) rc = fail(ctx, JDSP_EHIP, "jdsp_vad_blocks: D2H", e);
+    if (!rc && zcr_host && (e = hipMemcpyAsync(zcr_host, d_z, n * 4, hipMemcpyDeviceToHost, s)) != hipSuccess) rc = fail(ctx, JDSP_EHIP, "jdsp_vad_blocks: D2H", e);
+    if ((e = hipStreamSynchronize(s)) != hipSuccess && !rc) rc = fail(ctx, JDSP_EHIP, "jdsp_vad_blocks: sync", e);
+    if (d_in) (void)hipFree(d_in);
+    if (d_v) (void)hipFree(d_v);
+    if (d_e) (void)hipFree(d_e);
+    if (d_z) (void)hipFree(d_z);
     return rc;
 }
 

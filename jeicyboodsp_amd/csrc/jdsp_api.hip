@@ -28,6 +28,16 @@ int ensure_stft1024_table(jdsp_ctx *ctx)
     return 0;
 }
 
+int ensure_vad_window(jdsp_ctx *ctx)
+{
+    if (ctx->vad_w_hi) return 0;
+    double w[512];
+    for (int i = 0; i < 512; i++) w[i] = (0.54 - 0.46 * cos(2 * 3.141592 * (512 + i) / (1024 - 1)));   // SS:131
+    JDSP_HIP(ctx, hipMalloc((void **)&ctx->vad_w_hi, sizeof(w)));
+    JDSP_HIP(ctx, hipMemcpy(ctx->vad_w_hi, w, sizeof(w), hipMemcpyHostToDevice));
+    return 0;
+}
+
 }  // namespace jdsp
 
 using jdsp::fail;
@@ -78,6 +88,7 @@ int jdsp_destroy(jdsp_ctx *ctx)
     if (ctx->stft1024_table) (void)hipFree(ctx->stft1024_table);
     for (auto &p : ctx->c2c_tw)
         if (p) (void)hipFree(p);
+    if (ctx->vad_w_hi) (void)hipFree(ctx->vad_w_hi);
     if (ctx->conv_tw4096) (void)hipFree(ctx->conv_tw4096);
     if (ctx->conv_tw8192) (void)hipFree(ctx->conv_tw8192);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);

@@ -24,6 +24,7 @@ struct jdsp_ctx {
     float2 *stft1024_table = nullptr;
     double2 *c2c_tw[16] = {nullptr};   // by log2(n_fft)
     float2 *conv_tw4096 = nullptr, *conv_tw8192 = nullptr;
+    double *vad_w_hi = nullptr;        // second half of the FP64 Hamming window
 };
 
 namespace jdsp {
@@ -84,6 +85,7 @@ int launch_denoise(hipStream_t s, int mode, int k_opt, const short *pcm, long n_
                    const DenoiseState *st_in, DenoiseState *st_out, const int *ver, const float *noise_rows,
                    const float2 *table, short *out, float *precast);
 int ensure_stft1024_table(jdsp_ctx *ctx);
+int ensure_vad_window(jdsp_ctx *ctx);
 // fastconv_kernels.hip
 // (fastconv) Sample `pos` of this call's stream (pos < 0: history carried in the handle).  Samples of
 // the first n_hist blocks of a stream never reach the transform in the reference (its queue

@@ -1,0 +1,141 @@
+"""GPU tests of the host side above the C ABI:
+  * compat_selftest drives the reference-signature functions (FFTProcess, Bitrev,
+    VoiceActivityDetection, EstimateNoiseSpectrum, SpectralSubtraction, WienerFiltering,
+    AnalySisFreqDomain, MelFilterBankInit, MFCCFeatureExtraction) one block per call, exactly as
+    the reference main()s do;
+  * the jdsp_* drivers keep the reference programs' command lines and file formats (44-byte
+    header skip or not, stale-tail final block, raw double[12] feature files, list file).
+Both are compared with the CPU oracle on the same bytes."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+COMPAT = os.path.join(ROOT, "jeicyboodsp_amd", "compat")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def built():
+    if not os.path.exists(os.path.join(COMPAT, "compat_selftest")):
+        subprocess.check_call(["make", "-s", "-C", COMPAT])
+
+
+def run(prog, *args):
+    subprocess.run([os.path.join(COMPAT, prog)] + [str(a) for a in args], check=True,
+                   stdout=subprocess.DEVNULL, timeout=300)
+
+
+def speechlike(seed, n_blocks, block=512):
+    rng = np.random.default_rng(seed)
+    x = rng.normal(0, 3000, n_blocks * block)
+    q = min(14, n_blocks // 2) * block
+    x[:q] = rng.normal(0, 45, q)
+    if n_blocks >= 44:
+        x[30 * block:30 * block + q] = rng.normal(0, 45, q)
+    return np.clip(np.rint(x), -32768, 32767).astype(np.int16)
+
+
+def rir(golden_dir):
+    g = np.load(os.path.join(golden_dir, "rir_taps.npz"), allow_pickle=False)
+    taps = np.zeros(int(g["n_taps"]))
+    taps[g["index"]] = g["value"]
+    return taps
+
+
+@pytest.mark.parametrize("what,mode", [("ss", 0), ("wf", 1)])
+def test_compat_denoise_per_block_calls(tmp_path, oracle, what, mode):
+    pcm = speechlike(1, 60)
+    pcm.tofile(tmp_path / "in.raw")
+    run("compat_selftest", what, tmp_path / "in.raw", tmp_path / "out.bin")
+    got = np.fromfile(tmp_path / "out.bin", np.int16)
+    want, _ = oracle.denoise_stream(mode, pcm)
+    assert got.shape == want.shape
+    assert np.abs(got.astype(np.int32) - want.astype(np.int32)).max() <= 1
+
+
+def test_compat_fft_bitrev(tmp_path, oracle, golden_dir):
+    g = np.load(os.path.join(golden_dir, "fftalg_512.npz"), allow_pickle=False)
+    g["pcm"].tofile(tmp_path / "in.raw")
+    run("compat_selftest", "fft", tmp_path / "in.raw", tmp_path / "out.bin")
+    raw = np.fromfile(tmp_path / "out.bin", np.uint8)
+    spec = raw[:4 * 512 * 16].view(np.complex128).reshape(4, 512)
+    bits = raw[4 * 512 * 16:].view(np.int16)
+    assert np.abs(spec - g["fwd"]).max() < 1e-9 * np.abs(g["fwd"]).max()
+    assert np.array_equal(bits, g["bitrev"])
+
+
+def test_compat_conv_and_mfcc(tmp_path, oracle, golden_dir):
+    taps = rir(golden_dir)
+    taps.tofile(tmp_path / "taps.f64")
+    pcm = speechlike(2, 24, 1024)
+    pcm.tofile(tmp_path / "in.raw")
+    run("compat_selftest", "conv", tmp_path / "in.raw", tmp_path / "conv.bin", tmp_path / "taps.f64")
+    got = np.fromfile(tmp_path / "conv.bin", np.int16)
+    want, _ = oracle.fastconv_stream(pcm, taps, 8192)
+    assert got.shape == want.shape and np.abs(got.astype(np.int32) - want.astype(np.int32)).max() <= 1
+    run("compat_selftest", "mfcc", tmp_path / "in.raw", tmp_path / "mfcc.bin")
+    feats = np.fromfile(tmp_path / "mfcc.bin", np.float64).reshape(-1, 12)
+    wantf = oracle.mfcc_stream(oracle.mfcc_native_cfg(), pcm)
+    assert feats.shape == wantf.shape
+    assert (np.abs(feats - wantf) / np.abs(wantf).max(axis=1, keepdims=True)).max() < 1e-5
+
+
+def test_driver_specsub_wiener_no_header_and_stale_tail(tmp_path, oracle):
+    pcm = speechlike(3, 50)
+    ragged = np.concatenate([pcm, np.array([7, -9, 11] * 50, np.int16)])          # 150 extra samples
+    ragged.tofile(tmp_path / "in.raw")
+    # what the reference's fread loop sees: the last block keeps the previous block's tail (SS:94)
+    last = pcm[-512:].copy()
+    last[:150] = ragged[-150:]
+    seen = np.concatenate([pcm, last])
+    for prog, mode in (("jdsp_specsub", 0), ("jdsp_wiener", 1)):
+        run(prog, tmp_path / "in.raw", tmp_path / "out.raw")
+        got = np.fromfile(tmp_path / "out.raw", np.int16)
+        want, _ = oracle.denoise_stream(mode, seen)
+        assert got.shape == want.shape == ((51 - 2) * 512,)
+        assert np.abs(got.astype(np.int32) - want.astype(np.int32)).max() <= 1
+
+
+def test_driver_fftalg_and_conv3d_skip_wav_header(tmp_path, oracle, golden_dir):
+    g = np.load(os.path.join(golden_dir, "fftalg_512.npz"), allow_pickle=False)
+    with open(tmp_path / "in.wav", "wb") as f:
+        f.write(bytes(range(44)))
+        f.write(g["pcm"].tobytes())
+    run("jdsp_fftalg", tmp_path / "in.wav", tmp_path / "out.raw")
+    got = np.fromfile(tmp_path / "out.raw", np.int16)
+    assert got.shape == g["main_out"].shape
+    assert np.abs(got.astype(np.int32) - g["main_out"].astype(np.int32)).max() <= 1      # vs the reference's own output
+    taps = rir(golden_dir)
+    taps.tofile(tmp_path / "taps.f64")
+    pcm = speechlike(4, 20, 1024)
+    with open(tmp_path / "c.wav", "wb") as f:
+        f.write(bytes(44))
+        f.write(pcm.tobytes())
+    run("jdsp_conv3d", tmp_path / "c.wav", tmp_path / "c.raw", tmp_path / "taps.f64")
+    got = np.fromfile(tmp_path / "c.raw", np.int16)
+    want, _ = oracle.fastconv_stream(pcm, taps, 8192)
+    assert got.shape == want.shape and np.abs(got.astype(np.int32) - want.astype(np.int32)).max() <= 1
+
+
+def test_driver_mfcc_list_file_carries_state_between_files(tmp_path, oracle):
+    cfg = oracle.mfcc_native_cfg()
+    a, b = speechlike(5, 6, 1024), speechlike(6, 4, 1024)
+    for name, x in (("a.wav", a), ("b.wav", b)):
+        with open(tmp_path / name, "wb") as f:
+            f.write(bytes(44))
+            f.write(x.tobytes())
+    with open(tmp_path / "list.txt", "w") as f:
+        f.write("%s %s\n%s %s\n" % (tmp_path / "a.wav", tmp_path / "a.mfc", tmp_path / "b.wav", tmp_path / "b.mfc"))
+    run("jdsp_mfcc", tmp_path / "list.txt")
+    fa = np.fromfile(tmp_path / "a.mfc", np.float64).reshape(-1, 12)
+    fb = np.fromfile(tmp_path / "b.mfc", np.float64).reshape(-1, 12)
+    wa = oracle.mfcc_stream(cfg, a)                                     # first file: 2B-1 vectors
+    # second file: the keep buffer still holds a's last 512 samples and nothing is skipped (MFCC:95,198)
+    wb = oracle.mfcc_frames(cfg, np.concatenate([a[-512:], b]), 2 * 4)
+    assert fa.shape == wa.shape == (11, 12) and fb.shape == wb.shape == (8, 12)
+    for got, want in ((fa, wa), (fb, wb)):
+        assert (np.abs(got - want) / np.abs(want).max(axis=1, keepdims=True)).max() < 1e-5
