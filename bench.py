@@ -28,14 +28,17 @@ BYTES_PER_FRAME = 512 * 2 + 1024 * 8          # 9,216 B algorith
 HBM_PEAK_GBS = 8000.0                         # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
-def synth_pcm(rank, n_frames):
-    """SURVEY.md §8d synthetic input: default_rng(0).normal(0,3000) int16, (B+1)*512 samples.
-    Rank r takes frames [r*B, (r+1)*B) of the global stream: its slice plus a 512-sample halo."""
+def synth_pcm(rank, n_frames, world=1):
+    """SURVEY.md §8d synthetic input: default_rng(0).normal(0,3000) int16.  The global stream has
+    world*B frames = (world*B+1)*512 samples; rank r owns frames [r*B, (r+1)*B) and reads its slice
+    plus the 512-sample halo (jeicyboodsp_amd.sharding.stft_shard) -- no communication."""
     import numpy as np
+    from jeicyboodsp_amd import sharding
+    s = sharding.stft_shard(n_frames * world, rank, world, N_FFT, HOP)
+    assert s.count == n_frames
     rng = np.random.default_rng(0)
-    total = 512 * (n_frames * (rank + 1) + 1)
-    x = np.clip(np.rint(rng.normal(0.0, 3000.0, total)), -32768, 32767).astype(np.int16)
-    return x[512 * n_frames * rank:]
+    x = np.clip(np.rint(rng.normal(0.0, 3000.0, s.sample_first + s.sample_count)), -32768, 32767).astype(np.int16)
+    return x[s.sample_first:]
 
 
 def cpu_baseline(seconds=10.0):
@@ -116,7 +119,7 @@ def main():
 
     eng = jeicyboodsp_amd.Engine(local_rank)
     B = args.frames
-    pcm = torch.from_numpy(synth_pcm(rank, B)[: 512 * (B + 1)].copy()).to(dev)
+    pcm = torch.from_numpy(synth_pcm(rank, B, world)[: 512 * (B + 1)].copy()).to(dev)
     spec = torch.empty((B, N_FFT), dtype=torch.complex64, device=dev)
 
     def barrier():
@@ -139,12 +142,12 @@ def main():
 
     gather_ms = None
     if args.gather and dist is not None:
-        out = torch.empty((world * B, N_FFT), dtype=torch.complex64, device=dev)
-        dist.all_gather_into_tensor(torch.view_as_real(out), torch.view_as_real(spec))
+        from jeicyboodsp_amd import sharding
+        sharding.all_gather_rows(spec, [B] * world, dist)
         barrier()
         t1 = time.perf_counter()
         for _ in range(5):
-            dist.all_gather_into_tensor(torch.view_as_real(out), torch.view_as_real(spec))
+            sharding.all_gather_rows(spec, [B] * world, dist)
         barrier()
         gather_ms = (time.perf_counter() - t1) / 5 * 1e3
 

@@ -1,0 +1,79 @@
+"""Data-parallel sharding of the spectral path over the GPUs of one node.
+
+Frames, convolution blocks and utterances are independent once each shard carries
+its input halo, so there is NO data-path collective: rank r transforms its own
+contiguous slice.  The only collective is the optional gather of the outputs
+(RCCL all_gather when the caller wants the whole buffer on every rank).
+
+Pure index arithmetic + torch.distributed calls; works with any backend
+(tests run it on CPU with gloo, world_size 2).
+"""
+from collections import namedtuple
+
+Shard = namedtuple("Shard", "first count sample_first sample_count")
+
+
+def split_even(n, rank, world):
+    """Contiguous, balanced split of n units: the first n % world ranks get one more."""
+    base, rem = divmod(n, world)
+    first = rank * base + min(rank, rem)
+    return first, base + (1 if rank < rem else 0)
+
+
+def stft_shard(n_frames, rank, world, n_fft=1024, hop=512):
+    """Frames [first, first+count) and the PCM slice they need: frame f covers
+    samples [hop*f, hop*f + n_fft), so neighbouring shards overlap by n_fft - hop samples."""
+    first, count = split_even(n_frames, rank, world)
+    if count == 0:
+        return Shard(first, 0, hop * first, 0)
+    return Shard(first, count, hop * first, hop * (count - 1) + n_fft)
+
+
+def fastconv_shard(n_out_blocks, rank, world, block, n_taps):
+    """Output blocks [first, first+count) of an overlap-save stream (numbered from the first
+    EMITTED block) and the input samples they need: n_taps - 1 samples of history in front."""
+    first, count = split_even(n_out_blocks, rank, world)
+    if count == 0:
+        return Shard(first, 0, first * block, 0)
+    return Shard(first, count, first * block - (n_taps - 1), count * block + (n_taps - 1))
+
+
+def utterance_shard(frames_per_utt, rank, world):
+    """Whole utterances per rank, contiguous, balanced by frame count (prefix-sum cut points).
+    Returns (first_utt, n_utt)."""
+    prefix = [0]
+    for f in frames_per_utt:
+        prefix.append(prefix[-1] + f)
+    total = prefix[-1]
+    cuts = [0]
+    u = 0
+    for r in range(1, world):
+        target = total * r / world
+        while u < len(frames_per_utt) and abs(prefix[u + 1] - target) <= abs(prefix[u] - target):
+            u += 1
+        cuts.append(u)
+    cuts.append(len(frames_per_utt))
+    return cuts[rank], cuts[rank + 1] - cuts[rank]
+
+
+def all_gather_rows(local, counts, dist, group=None):
+    """Gathers row-sharded tensors of unequal length: local is [counts[rank], ...]; returns
+    [sum(counts), ...] on every rank.  Shards are padded to the longest so a single
+    all_gather_into_tensor moves everything (one large collective, not world_size small ones)."""
+    import torch
+    world = len(counts)
+    longest = max(counts)
+    tail = tuple(local.shape[1:])
+    padded = local
+    if local.shape[0] != longest:
+        padded = torch.zeros((longest,) + tail, dtype=local.dtype, device=local.device)
+        padded[: local.shape[0]] = local
+    out = torch.empty((world * longest,) + tail, dtype=local.dtype, device=local.device)
+    real = padded.is_complex()
+    if real:
+        dist.all_gather_into_tensor(torch.view_as_real(out), torch.view_as_real(padded.contiguous()), group=group)
+    else:
+        dist.all_gather_into_tensor(out, padded.contiguous(), group=group)
+    if all(c == longest for c in counts):
+        return out
+    return torch.cat([out[r * longest: r * longest + counts[r]] for r in range(world)])
