@@ -1,6 +1,6 @@
 // compat_selftest.cpp -- drives the reference-signature functions exactly the way the
 // reference main()s do (one block per call) and dumps what they return, for tests/ to compare
-// with the oracle.  usage: compat_selftest <ss|wf|conv|mfcc|fft> in.raw out.bin [taps.f64]
+// with the CPU checker.  usage: compat_selftest <ss|wf|conv|mfcc|fft> in.raw out.bin [taps.f64]
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
