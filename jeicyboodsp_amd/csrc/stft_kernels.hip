@@ -4,7 +4,7 @@
 // WienerFilter_final.cpp:181-193): int16 -> double, * Hamming, 1024-point
 // forward c2c DFT of the real frame, all 1024 bins kept.
 //
-// Mapping: one wavefront owns K consecutive frames (K = 1 by default).  A frame
+// Mapping: one wavefront owns K consecutive frames (K = 2 by default).  A frame
 // is a 512-point complex FFT in the wave's registers/LDS (wave_fft512.h) plus a
 // split step; the 8 KB spectrum leaves as eight fully coalesced 1 KB
 // nontemporal wave stores.  HBM-bound: 1 KB in + 8 KB out per frame.
@@ -25,7 +25,7 @@ namespace jdsp {
 
 // ---- build-time variants (tools/tune_stft.py A/Bs them on the GPU) -------------------
 #ifndef JDSP_STFT_K
-#define JDSP_STFT_K 1             // consecutive frames per wavefront ("stft.frames_per_wave" = 0 picks this)
+#define JDSP_STFT_K 2             // consecutive frames per wavefront ("stft.frames_per_wave" = 0 picks this)
 #endif
 #ifndef JDSP_STFT_MINWAVES
 #define JDSP_STFT_MINWAVES 4      // __launch_bounds__ 2nd arg: waves per SIMD the register budget must allow

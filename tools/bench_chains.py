@@ -1,0 +1,131 @@
+#!/usr/bin/env python3
+"""Secondary figures: the chains downstream of the STFT, each timed with HIP
+events on the stream it runs on, inputs resident in HBM.  One JSON line per chain.
+
+    python tools/bench_chains.py [--iters 20]
+
+These are reported next to, never instead of, bench.py's headline metric."""
+import argparse
+import json
+import os
+import statistics
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import jeicyboodsp_amd  # noqa: E402
+
+HBM_PEAK = 8000.0       # GB/s
+FP32_PEAK = 157.3       # TFLOP/s vector
+
+
+def timed(fn, iters, rounds=5):
+    fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(rounds):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(iters):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        ts.append(a.elapsed_time(b) / iters)
+    return statistics.median(ts)
+
+
+def pcm_of(rng, n, sigma=3000.0):
+    return np.clip(np.rint(rng.normal(0, sigma, n)), -32768, 32767).astype(np.int16)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--only", default="")
+    a = ap.parse_args()
+    eng = jeicyboodsp_amd.Engine(0)
+    rng = np.random.default_rng(0)
+    out = []
+
+    def report(name, ms, units, unit_name, bytes_per_unit, flops_per_unit, note=""):
+        rate = units / (ms * 1e-3)
+        gbs = rate * bytes_per_unit / 1e9
+        tf = rate * flops_per_unit / 1e12
+        line = {"chain": name, "ms": ms, "units": units, "unit": unit_name, "rate_per_s": rate,
+                "algorithmic_GBps": gbs, "hbm_frac": gbs / HBM_PEAK, "fft_TFLOPs": tf, "fp32_vector_frac": tf / FP32_PEAK,
+                "note": note}
+        out.append(line)
+        print(json.dumps(line), flush=True)
+
+    B = 65536
+    want = set(a.only.split(",")) if a.only else None
+
+    def on(n):
+        return want is None or n in want
+
+    if on("denoise"):
+        x = pcm_of(rng, B * 512)
+        x[:12 * 512] = pcm_of(rng, 12 * 512, 45.0)          # the estimate latches at block 10
+        t = torch.from_numpy(x).cuda()
+        for mode, nm in ((0, "specsub"), (1, "wiener")):
+            d = eng.denoiser(mode)
+            d.process(t)                                        # sizes the workspace
+
+            def step():
+                d.reset()
+                d.process(t)
+            ms = timed(step, a.iters)
+            # 512 int16 in + 512 int16 out per block; forward + inverse 1024-pt real transforms
+            report("denoise_" + nm, ms, B, "blocks", 2048, 2 * 5 * 512 * 9 + 2 * 512 * 14,
+                   "VAD + plan + noise estimate + fused window/FFT/gain/IFFT/OLA, 65,536 blocks of 512")
+            d.close()
+    if on("mfcc"):
+        x = torch.from_numpy(pcm_of(rng, 512 * (B + 1))).cuda()
+        m = eng.mfcc()
+        ms = timed(lambda: m.frames(x, B), a.iters)
+        report("mfcc_native_1024_512_38ch", ms, B, "frames", 1024 + 96, 5 * 512 * 9 + 512 * 14 + 2 * 1024 + 2 * 38 * 12,
+               "pre-emphasis/Hamming/FFT/mel/ln/DCT/lifter, 65,536 frames, 12 doubles out")
+        m.close()
+        x16 = torch.from_numpy(pcm_of(rng, 160 * (B - 1) + 400)).cuda()
+        m = eng.mfcc(win_len=400, hop=160, n_fft=512, n_chan=40, n_cep=13, half_rate=8000.0)
+        ms = timed(lambda: m.frames(x16, B), a.iters)
+        report("mfcc_400_160_512fft_40mel", ms, B, "frames", 320 + 104, 5 * 512 * 9 + 512 * 14, "BASELINE config 4 framing")
+        m.close()
+    if on("fastconv"):
+        nb = 4096
+        taps = rng.normal(size=7169) * 0.01
+        x = torch.from_numpy(pcm_of(rng, nb * 1024, 2000.0)).cuda()
+        fc = eng.fastconv(taps, 8192)
+
+        def step():
+            fc.reset()
+            fc.process(x)
+        ms = timed(step, max(a.iters // 4, 3))
+        report("fastconv_8192_native", ms, nb - 7, "blocks", 4096, 2 * 5 * 4096 * 12 + 2 * 4096 * 14 + 8192 * 6,
+               "reference-native: 7169 taps, 1024-sample blocks, one 512-thread workgroup per block")
+        fc.close()
+        nb = 65536
+        h2 = rng.normal(size=(2, 256)) * 0.1
+        x = torch.from_numpy(pcm_of(rng, nb * 769, 2000.0)).cuda()
+        fc = eng.fastconv(h2, 1024)
+
+        def step2():
+            fc.reset()
+            fc.process(x)
+        ms = timed(step2, a.iters)
+        report("fastconv_1024_hrir_pair", ms, nb - 1, "blocks", 4614, 3 * 5 * 512 * 9 + 3 * 512 * 14 + 2 * 1024 * 6,
+               "BASELINE config 2: 256-tap pair, 769-sample blocks, mono in -> 2 ears out")
+        fc.close()
+    if on("fft"):
+        n = 65536
+        z = torch.from_numpy(rng.normal(size=(n, 512)) + 1j * rng.normal(size=(n, 512))).cuda()
+        ms = timed(lambda: eng.fft_process(z), max(a.iters // 4, 3))
+        report("fftprocess_f64_512", ms, n, "transforms", 2 * 512 * 16, 5 * 512 * 9, "FFTAlgorithm_ver2 FFTProcess, FP64, batch 65,536")
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()

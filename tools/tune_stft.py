@@ -40,6 +40,9 @@ def main():
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--frames", type=int, default=65536)
+    ap.add_argument("--sustain-ms", type=float, default=0.0,
+                    help="also time every case under a sustained load: run it back to back for this long, "
+                         "report the mean of the second half (power management settles after ~2 ms)")
     a = ap.parse_args()
     B = a.frames
     rng = np.random.default_rng(0)
@@ -78,10 +81,31 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             times[(n, f)].append(e0.elapsed_time(e1) / a.iters * 1e3)
+    sustained = {}
+    if a.sustain_ms > 0:
+        for n, f, lib, h in cases:
+            est = statistics.median(times[(n, f)]) * 1e-3            # ms per launch
+            k = max(int(a.sustain_ms / est / 2), 10)
+            evs = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+            evs[0].record()
+            for _ in range(k):
+                run(lib, h, f)
+            evs[1].record()
+            for _ in range(k):
+                run(lib, h, f)
+            evs[2].record()
+            torch.cuda.synchronize()
+            sustained[(n, f)] = (evs[0].elapsed_time(evs[1]) / k * 1e3, evs[1].elapsed_time(evs[2]) / k * 1e3)
+            torch.cuda._sleep(int(2e8))                              # let the chip cool off between cases
+            torch.cuda.synchronize()
     print("%-28s %5s %9s %9s %9s" % ("variant", "fpw", "med_us", "min_us", "GB/s@med"))
     for (n, f), t in sorted(times.items(), key=lambda kv: statistics.median(kv[1])):
         med = statistics.median(t)
-        print("%-28s %5d %9.1f %9.1f %9.0f" % (n, f, med, min(t), 9216.0 * B / med / 1e3))
+        extra = ""
+        if (n, f) in sustained:
+            s1, s2 = sustained[(n, f)]
+            extra = "   sustained: 1st half %.1f us, 2nd half %.1f us (%.0f GB/s)" % (s1, s2, 9216.0 * B / s2 / 1e3)
+        print("%-28s %5d %9.1f %9.1f %9.0f%s" % (n, f, med, min(t), 9216.0 * B / med / 1e3, extra))
 
 
 if __name__ == "__main__":
