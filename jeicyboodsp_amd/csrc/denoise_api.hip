@@ -5,11 +5,12 @@ using jdsp::fail;
 
 static void free_workspace(jdsp_denoise *h)
 {
-    void *p[] = {h->flags, h->nrun, h->ver, h->events, h->dbg_energy, h->dbg_zcr, h->mag, h->rows};
+    void *p[] = {h->flags, h->ev_n, h->ver_base, h->snap_mask, h->events, h->dbg_energy, h->dbg_zcr, h->mag, h->rows};
     for (void *q : p)
         if (q) (void)hipFree(q);
     h->flags = nullptr;
-    h->nrun = h->ver = h->events = nullptr;
+    h->ev_n = h->ver_base = h->events = nullptr;
+    h->snap_mask = nullptr;
     h->dbg_energy = nullptr;
     h->dbg_zcr = nullptr;
     h->mag = h->rows = nullptr;
@@ -99,8 +100,9 @@ int jdsp_denoise_reserve(jdsp_denoise *h, long max_blocks)
     free_workspace(h);
     const size_t n = (size_t)max_blocks;
     hipError_t e = hipMalloc((void **)&h->flags, n);
-    if (e == hipSuccess) e = hipMalloc((void **)&h->nrun, n * sizeof(int));
-    if (e == hipSuccess) e = hipMalloc((void **)&h->ver, n * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc((void **)&h->ev_n, n * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc((void **)&h->ver_base, (n / 64 + 1) * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc((void **)&h->snap_mask, (n / 64 + 1) * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMalloc((void **)&h->events, n * sizeof(int));
     if (e == hipSuccess) e = hipMalloc((void **)&h->dbg_energy, n * sizeof(long long));
     if (e == hipSuccess) e = hipMalloc((void **)&h->dbg_zcr, n * sizeof(int));
@@ -134,11 +136,12 @@ int jdsp_denoise_process_dev(jdsp_denoise *h, const int16_t *pcm_dev, long n_blo
     jdsp::DenoiseState *st_out = h->st[h->cur ^ 1];
     hipStream_t s = ctx->stream;
     if (jdsp::launch_vad(s, pcm_dev, n_blocks, h->w_hi, h->flags, h->dbg_energy, h->dbg_zcr) ||
-        jdsp::launch_denoise_plan(s, h->flags, n_blocks, st_in, st_out, h->nrun, h->ver, h->events, h->plan) ||
-        jdsp::launch_noise_estimate(s, pcm_dev, n_blocks, st_in, st_out, h->events, h->nrun, h->plan,
+        jdsp::launch_denoise_plan(s, h->flags, n_blocks, st_in, st_out, h->ver_base, h->snap_mask, h->events, h->ev_n,
+                                  h->plan) ||
+        jdsp::launch_noise_estimate(s, pcm_dev, n_blocks, st_in, st_out, h->events, h->ev_n, h->plan,
                                     ctx->stft1024_table, h->mag, h->rows) ||
-        jdsp::launch_denoise(s, h->mode, h->opt_k, pcm_dev, n_blocks, h->calls, st_in, st_out, h->ver, h->rows,
-                             ctx->stft1024_table, out_dev, precast_dev))
+        jdsp::launch_denoise(s, h->mode, h->opt_k, pcm_dev, n_blocks, h->calls, st_in, st_out, h->ver_base,
+                             h->snap_mask, h->rows, ctx->stft1024_table, out_dev, precast_dev))
         return fail(ctx, JDSP_EHIP, "denoise launch", hipGetLastError());
     h->cur ^= 1;
     h->calls += n_blocks;
@@ -207,11 +210,12 @@ int jdsp_denoise_apply(jdsp_denoise *h, const int16_t *pcm_host, long n_blocks, 
     jdsp::DenoiseState *st_in = h->st[h->cur], *st_out = h->st[h->cur ^ 1];
     if (e == hipSuccess) e = hipMemcpyAsync(d_in, pcm_host, in_b, hipMemcpyHostToDevice, s);
     if (e == hipSuccess) e = hipMemcpyAsync(h->rows, row, sizeof(row), hipMemcpyHostToDevice, s);
-    if (e == hipSuccess) e = hipMemsetAsync(h->ver, 0, (size_t)n_blocks * sizeof(int), s);      // every block uses row 0
+    if (e == hipSuccess) e = hipMemsetAsync(h->ver_base, 0, ((size_t)n_blocks / 64 + 1) * sizeof(int), s);   // every block uses row 0
+    if (e == hipSuccess) e = hipMemsetAsync(h->snap_mask, 0, ((size_t)n_blocks / 64 + 1) * sizeof(unsigned long long), s);
     if (e == hipSuccess) e = hipMemcpyAsync(st_out, st_in, sizeof(jdsp::DenoiseState), hipMemcpyDeviceToDevice, s);
     if (e != hipSuccess) rc = fail(ctx, JDSP_EHIP, "jdsp_denoise_apply: staging", e);
-    if (!rc && jdsp::launch_denoise(s, h->mode, h->opt_k, d_in, n_blocks, h->calls, st_in, st_out, h->ver, h->rows,
-                                    ctx->stft1024_table, d_out, d_pre))
+    if (!rc && jdsp::launch_denoise(s, h->mode, h->opt_k, d_in, n_blocks, h->calls, st_in, st_out, h->ver_base,
+                                    h->snap_mask, h->rows, ctx->stft1024_table, d_out, d_pre))
         rc = fail(ctx, JDSP_EHIP, "denoise launch", hipGetLastError());
     if (!rc && n_out > 0 && (e = hipMemcpyAsync(out_host, d_out, (size_t)n_out * 1024, hipMemcpyDeviceToHost, s)) != hipSuccess)
         rc = fail(ctx, JDSP_EHIP, "jdsp_denoise_apply: D2H", e);

@@ -4,9 +4,10 @@
 // static state (SS:92-113).  Here a whole batch of blocks goes through five launches:
 //
 //   vad_kernel          A11  VoiceActivityDetection per block (SS:121-156): integer/FP64, bit-exact
-//   plan_kernel         A13  main()'s run-length counter (SS:98-109) as a prefix scan: run length
-//                            n[j], the list of blocks that call EstimateNoiseSpectrum (n >= 2) and,
-//                            per block, which latched estimate (n == 10, SS:189-193) is current
+//   plan_kernel         A13  main()'s run-length counter (SS:98-109) as prefix scans over 64-block
+//                            bit masks: the list of blocks that call EstimateNoiseSpectrum (run
+//                            length >= 2) and, per block, which latched estimate (run length == 10,
+//                            SS:189-193) is current
 //   noise_mag_kernel    A12  |FFT(window * [previous block, block])| for the listed blocks (SS:168-183)
 //   noise_scan_kernel   A12  the running average (SS:182-187), sequential over the list, one bin per thread
 //   denoise_kernel      A8/A9/A10  window -> FFT -> gain -> IFFT -> overlap-add -> (short), fused;
@@ -60,7 +61,16 @@ __global__ __launch_bounds__(64) void vad_kernel(const short *__restrict__ pcm, 
 }
 
 // ---------------------------------------------------------------------------------------
-// A13 bookkeeping.  One workgroup of 1024 threads, each owning a contiguous slice of blocks.
+// A13 bookkeeping.  One workgroup of 1024 threads; each thread owns 64 consecutive blocks,
+// whose voice flags it packs into one 64-bit mask, so every pass after the single load runs
+// in registers.  Batches longer than 65,536 blocks are walked tile by tile with the carries
+// (run length, event and latch counts) kept in LDS.
+//
+// Outputs: events[e] / ev_n[e] = block index and run length of the e-th EstimateNoiseSpectrum
+// call (run length >= 2, SS:103-105); per 64-block slice s, ver_base[s] = number of latches
+// (run length == 10, SS:189) before the slice and snap_mask[s] = which of its blocks latch, so
+//     version(j) = ver_base[j >> 6] + popcount(snap_mask[j >> 6] & bits 0..(j & 63))
+// (the estimate latched AT block j already applies to block j: main() estimates first).
 struct RunSummary { int has_voice, trailing; };
 
 __device__ __forceinline__ RunSummary combine(RunSummary a, RunSummary b)
@@ -71,75 +81,113 @@ __device__ __forceinline__ RunSummary combine(RunSummary a, RunSummary b)
     return r;
 }
 
+__device__ __forceinline__ int version_of(const int *__restrict__ ver_base,
+                                          const unsigned long long *__restrict__ snap_mask, long j)
+{
+    const unsigned long long m = snap_mask[j >> 6] & (~0ull >> (63 - (int)(j & 63)));
+    return ver_base[j >> 6] + __popcll(m);
+}
+
 __global__ __launch_bounds__(1024) void plan_kernel(const unsigned char *__restrict__ flags, long n_blocks,
                                                     const DenoiseState *__restrict__ st_in, DenoiseState *st_out,
-                                                    int *__restrict__ nrun, int *__restrict__ ver,
-                                                    int *__restrict__ events, DenoisePlan *plan)
+                                                    int *__restrict__ ver_base,
+                                                    unsigned long long *__restrict__ snap_mask,
+                                                    int *__restrict__ events, int *__restrict__ ev_n,
+                                                    DenoisePlan *plan)
 {
     __shared__ RunSummary sum[1024];
     __shared__ int cnt_ev[1024], cnt_sn[1024];
+    __shared__ int carry_run, carry_ev, carry_sn;
     const int t = threadIdx.x;
-    const long chunk = (n_blocks + 1023) / 1024;
-    const long a = (long)t * chunk;
-    const long b = a + chunk < n_blocks ? a + chunk : n_blocks;
-
-    RunSummary mine = {0, 0};
-    for (long j = a; j < b; j++) {
-        if (flags[j]) { mine.has_voice = 1; mine.trailing = 0; }
-        else mine.trailing++;
-    }
-    sum[t] = mine;
+    if (t == 0) { carry_run = st_in->run_len; carry_ev = 0; carry_sn = 0; }
     __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {                     // inclusive Hillis-Steele scan
-        RunSummary v = sum[t];
-        if (t >= o) v = combine(sum[t - o], v);
-        __syncthreads();
-        sum[t] = v;
-        __syncthreads();
-    }
-    const int run_in = st_in->run_len;
-    int r = run_in;                                           // run length entering my slice
-    if (t > 0) r = sum[t - 1].has_voice ? sum[t - 1].trailing : run_in + sum[t - 1].trailing;
-    const int r_start = r;
 
-    int ne = 0, ns = 0;
-    for (long j = a; j < b; j++) {
-        if (flags[j]) r = 0;
-        else {
-            r++;
-            ne += (r >= 2);                                   // SS:103-105
-            ns += (r == 10);                                  // SS:189
+    for (long tile0 = 0; tile0 < n_blocks; tile0 += 65536) {
+        const long a = tile0 + (long)t * 64;
+        long left = n_blocks - a;
+        const int cnt = left >= 64 ? 64 : (left > 0 ? (int)left : 0);
+        unsigned long long V = 0;                               // bit i: block a+i is voice
+        if (cnt == 64 && (((uintptr_t)(flags + a)) & 15u) == 0) {
+            const uint4 *p = reinterpret_cast<const uint4 *>(flags + a);
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const uint4 w = p[q];
+                const unsigned int d[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    // the four 0/1 bytes of d[k] -> 4 adjacent bits
+                    const unsigned int nib = ((d[k] & 0x01010101u) * 0x01020408u) >> 24;
+                    V |= (unsigned long long)(nib & 15u) << (16 * q + 4 * k);
+                }
+            }
+        } else {
+            for (int i = 0; i < cnt; i++) V |= (unsigned long long)(flags[a + i] != 0) << i;
         }
-    }
-    cnt_ev[t] = ne;
-    cnt_sn[t] = ns;
-    __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {
-        int ve = cnt_ev[t], vs = cnt_sn[t];
-        if (t >= o) { ve += cnt_ev[t - o]; vs += cnt_sn[t - o]; }
+        RunSummary mine;
+        mine.has_voice = V != 0;
+        mine.trailing = V ? (cnt - 1) - (63 - __clzll(V)) : cnt;
+        sum[t] = mine;
         __syncthreads();
-        cnt_ev[t] = ve;
-        cnt_sn[t] = vs;
-        __syncthreads();
-    }
-    int eo = cnt_ev[t] - ne, so = cnt_sn[t] - ns;             // exclusive offsets
-    r = r_start;
-    for (long j = a; j < b; j++) {
-        if (flags[j]) { r = 0; nrun[j] = 0; }
-        else {
-            r++;
-            nrun[j] = r;
-            if (r >= 2) events[eo++] = (int)j;
-            if (r == 10) so++;
+        for (int o = 1; o < 1024; o <<= 1) {                    // inclusive Hillis-Steele scan
+            RunSummary v = sum[t];
+            if (t >= o) v = combine(sum[t - o], v);
+            __syncthreads();
+            sum[t] = v;
+            __syncthreads();
         }
-        ver[j] = so;                                          // the estimate latched AT block j already applies to it
+        const int run_in = carry_run;
+        int r = run_in;                                          // run length entering my slice
+        if (t > 0) r = sum[t - 1].has_voice ? sum[t - 1].trailing : run_in + sum[t - 1].trailing;
+        const int r_start = r;
+        unsigned long long E = 0, S = 0;                         // event / latch masks of my slice
+        for (int i = 0; i < cnt; i++) {
+            if ((V >> i) & 1ull) r = 0;
+            else {
+                r++;
+                if (r >= 2) E |= 1ull << i;
+                if (r == 10) S |= 1ull << i;
+            }
+        }
+        const int ne = __popcll(E), ns = __popcll(S);
+        cnt_ev[t] = ne;
+        cnt_sn[t] = ns;
+        __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) {
+            int ve = cnt_ev[t], vs = cnt_sn[t];
+            if (t >= o) { ve += cnt_ev[t - o]; vs += cnt_sn[t - o]; }
+            __syncthreads();
+            cnt_ev[t] = ve;
+            cnt_sn[t] = vs;
+            __syncthreads();
+        }
+        if (cnt > 0) {
+            ver_base[a >> 6] = carry_sn + cnt_sn[t] - ns;
+            snap_mask[a >> 6] = S;
+        }
+        if (E) {
+            int eo = carry_ev + cnt_ev[t] - ne;
+            r = r_start;
+            for (int i = 0; i < cnt; i++) {
+                if ((V >> i) & 1ull) r = 0;
+                else {
+                    r++;
+                    if (r >= 2) { events[eo] = (int)(a + i); ev_n[eo] = r; eo++; }
+                }
+            }
+        }
+        __syncthreads();
+        if (t == 0) {
+            carry_run = sum[1023].has_voice ? sum[1023].trailing : run_in + sum[1023].trailing;
+            carry_ev += cnt_ev[1023];
+            carry_sn += cnt_sn[1023];
+        }
+        __syncthreads();
     }
-    if (b == n_blocks && a < b) st_out->run_len = r;
-    if (t == 1023) {
-        plan->n_events = cnt_ev[1023];
-        plan->n_snap = cnt_sn[1023];
+    if (t == 0) {
+        st_out->run_len = carry_run;
+        plan->n_events = carry_ev;
+        plan->n_snap = carry_sn;
     }
-    if (n_blocks == 0 && t == 0) st_out->run_len = run_in;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -195,28 +243,31 @@ __global__ __launch_bounds__(64) void noise_mag_kernel(const short *__restrict__
     __shared__ __attribute__((aligned(16))) float2 lds[kWaveLdsComplex];
     __shared__ __attribute__((aligned(16))) unsigned int stage[256];
     const int lane = threadIdx.x;
-    const int e = blockIdx.x;
-    if (e >= plan->n_events) return;
-    const long j = events[e];
-    const u32x4 h0 = load_block(pcm, n_blocks, st_in, j - 1, lane);   // rgssKeepBuffer (SS:165-170)
-    const u32x4 h1 = load_block(pcm, n_blocks, st_in, j, lane);
+    const int n_events = plan->n_events;
+    if ((int)blockIdx.x >= n_events) return;
     FrameTables t;
     load_frame_tables(t, table, lane);
-    unsigned int raw[8];
-    relayout_half(stage, lane, h0, raw);
-    relayout_half(stage, lane, h1, raw + 4);
-    forward_to_lds(raw, t, lds, lane);
-    float *dst = mag + (size_t)e * 1024;
-    mag_store_j<0>(lds, lane, t.wsp, dst);
-    mag_store_j<1>(lds, lane, t.wsp, dst);
-    mag_store_j<2>(lds, lane, t.wsp, dst);
-    mag_store_j<3>(lds, lane, t.wsp, dst);
+    for (int e = blockIdx.x; e < n_events; e += gridDim.x) {
+        const long j = events[e];
+        const u32x4 h0 = load_block(pcm, n_blocks, st_in, j - 1, lane);   // rgssKeepBuffer (SS:165-170)
+        const u32x4 h1 = load_block(pcm, n_blocks, st_in, j, lane);
+        unsigned int raw[8];
+        relayout_half(stage, lane, h0, raw);
+        relayout_half(stage, lane, h1, raw + 4);
+        forward_to_lds(raw, t, lds, lane);
+        float *dst = mag + (size_t)e * 1024;
+        mag_store_j<0>(lds, lane, t.wsp, dst);
+        mag_store_j<1>(lds, lane, t.wsp, dst);
+        mag_store_j<2>(lds, lane, t.wsp, dst);
+        mag_store_j<3>(lds, lane, t.wsp, dst);
+        wave_lds_fence();
+    }
 }
 
 // A12, second half: rgsdAveragedNS += |X|; from run length 3 on, /= 2 (SS:182-187); at run
 // length 10 the average is latched (SS:189-193).  noise_rows[0] is the estimate carried in.
-__global__ __launch_bounds__(256) void noise_scan_kernel(const float *__restrict__ mag, const int *__restrict__ events,
-                                                         const int *__restrict__ nrun,
+__global__ __launch_bounds__(256) void noise_scan_kernel(const float *__restrict__ mag,
+                                                         const int *__restrict__ ev_n,
                                                          const DenoisePlan *__restrict__ plan,
                                                          const DenoiseState *__restrict__ st_in, DenoiseState *st_out,
                                                          float *__restrict__ noise_rows)
@@ -228,7 +279,7 @@ __global__ __launch_bounds__(256) void noise_scan_kernel(const float *__restrict
     const int n_events = plan->n_events;
     int row = 0;
     for (int e = 0; e < n_events; e++) {
-        const int n = nrun[events[e]];
+        const int n = ev_n[e];
         avg += mag[(size_t)e * 1024 + bin];
         if (n >= 3) avg *= 0.5f;
         if (n == 10) {
@@ -247,14 +298,14 @@ __global__ __launch_bounds__(256) void noise_scan_kernel(const float *__restrict
 template <int MODE>
 __device__ __forceinline__ float2 apply_gain(float2 x, float n)
 {
+    // hardware reciprocal / reciprocal square root (1 ulp): the bar is 1e-5, not IEEE division
     const float p = x.x * x.x + x.y * x.y;
     if (MODE == 0) {
-        const float mag = sqrtf(p);
-        if (mag == 0.0f) return make_float2(-n, 0.0f);
-        const float g = (mag - n) / mag;
+        if (p == 0.0f) return make_float2(-n, 0.0f);
+        const float g = 1.0f - n * __frsqrt_rn(p);           // (|X| - N) / |X|
         return make_float2(x.x * g, x.y * g);
     } else {
-        float r = (n * n) / p;
+        float r = (n * n) * __frcp_rn(p);                    // 0 * inf = NaN keeps the reference's 0/0
         if (r >= 1.0f) r = 1.0f;
         const float g = 1.0f - r;
         return make_float2(x.x * g, x.y * g);
@@ -314,8 +365,9 @@ __device__ __forceinline__ void denoise_frame(const unsigned int *raw, const Fra
 template <int MODE, int K>
 __global__ __launch_bounds__(64, JDSP_DENOISE_MINWAVES) void denoise_kernel(
     const short *__restrict__ pcm, long n_blocks, long calls_before, const DenoiseState *__restrict__ st_in,
-    DenoiseState *st_out, const int *__restrict__ ver, const float *__restrict__ noise_rows,
-    const float2 *__restrict__ table, short *__restrict__ out, float *__restrict__ precast)
+    DenoiseState *st_out, const int *__restrict__ ver_base, const unsigned long long *__restrict__ snap_mask,
+    const float *__restrict__ noise_rows, const float2 *__restrict__ table, short *__restrict__ out,
+    float *__restrict__ precast)
 {
     __shared__ __attribute__((aligned(16))) float2 lds[kWaveLdsComplex];
     __shared__ __attribute__((aligned(16))) unsigned int stage[256];
@@ -344,7 +396,7 @@ __global__ __launch_bounds__(64, JDSP_DENOISE_MINWAVES) void denoise_kernel(
 #pragma unroll
         for (int d = 0; d < 4; d++) tail[d] = make_float2(0.f, 0.f);
     } else {
-        denoise_frame<MODE>(raw, t, lds, lane, noise_rows + (size_t)ver[j0 - 1] * 1024, y);   // halo frame
+        denoise_frame<MODE>(raw, t, lds, lane, noise_rows + (size_t)version_of(ver_base, snap_mask, j0 - 1) * 1024, y);   // halo frame
 #pragma unroll
         for (int d = 0; d < 4; d++) tail[d] = y[d + 4];
     }
@@ -360,7 +412,7 @@ __global__ __launch_bounds__(64, JDSP_DENOISE_MINWAVES) void denoise_kernel(
 #pragma unroll
             for (int d = 0; d < 8; d++) y[d] = make_float2(0.f, 0.f);
         } else {
-            denoise_frame<MODE>(raw, t, lds, lane, noise_rows + (size_t)ver[j] * 1024, y);
+            denoise_frame<MODE>(raw, t, lds, lane, noise_rows + (size_t)version_of(ver_base, snap_mask, j) * 1024, y);
         }
         float2 o[4];
 #pragma unroll
@@ -400,41 +452,44 @@ int launch_vad(hipStream_t s, const short *pcm, long n_blocks, const double *w_h
 }
 
 int launch_denoise_plan(hipStream_t s, const unsigned char *flags, long n_blocks, const DenoiseState *st_in,
-                        DenoiseState *st_out, int *nrun, int *ver, int *events, DenoisePlan *plan)
+                        DenoiseState *st_out, int *ver_base, unsigned long long *snap_mask, int *events, int *ev_n,
+                        DenoisePlan *plan)
 {
-    hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(1024), 0, s, flags, n_blocks, st_in, st_out, nrun, ver, events,
-                       plan);
+    hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(1024), 0, s, flags, n_blocks, st_in, st_out, ver_base, snap_mask,
+                       events, ev_n, plan);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
 int launch_noise_estimate(hipStream_t s, const short *pcm, long n_blocks, const DenoiseState *st_in,
-                          DenoiseState *st_out, const int *events, const int *nrun, const DenoisePlan *plan,
+                          DenoiseState *st_out, const int *events, const int *ev_n, const DenoisePlan *plan,
                           const float2 *table, float *mag, float *noise_rows)
 {
-    if (n_blocks > 0)
-        hipLaunchKernelGGL(noise_mag_kernel, dim3((unsigned)n_blocks), dim3(64), 0, s, pcm, n_blocks, st_in, events,
-                           plan, table, mag);
-    hipLaunchKernelGGL(noise_scan_kernel, dim3(4), dim3(256), 0, s, mag, events, nrun, plan, st_in, st_out,
-                       noise_rows);
+    if (n_blocks > 0) {
+        const long grid = n_blocks < 4096 ? n_blocks : 4096;       // waves stride over the event list
+        hipLaunchKernelGGL(noise_mag_kernel, dim3((unsigned)grid), dim3(64), 0, s, pcm, n_blocks, st_in, events, plan,
+                           table, mag);
+    }
+    hipLaunchKernelGGL(noise_scan_kernel, dim3(4), dim3(256), 0, s, mag, ev_n, plan, st_in, st_out, noise_rows);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
 template <int MODE, int K>
 static void launch_dn(hipStream_t s, const short *pcm, long n_blocks, long calls_before, const DenoiseState *st_in,
-                      DenoiseState *st_out, const int *ver, const float *noise_rows, const float2 *table, short *out,
-                      float *precast)
+                      DenoiseState *st_out, const int *ver_base, const unsigned long long *snap_mask,
+                      const float *noise_rows, const float2 *table, short *out, float *precast)
 {
     long grid = ((n_blocks + K - 1) / K + 7) / 8 * 8;
     hipLaunchKernelGGL((denoise_kernel<MODE, K>), dim3((unsigned)grid), dim3(64), 0, s, pcm, n_blocks, calls_before,
-                       st_in, st_out, ver, noise_rows, table, out, precast);
+                       st_in, st_out, ver_base, snap_mask, noise_rows, table, out, precast);
 }
 
 int launch_denoise(hipStream_t s, int mode, int k_opt, const short *pcm, long n_blocks, long calls_before,
-                   const DenoiseState *st_in, DenoiseState *st_out, const int *ver, const float *noise_rows,
-                   const float2 *table, short *out, float *precast)
+                   const DenoiseState *st_in, DenoiseState *st_out, const int *ver_base,
+                   const unsigned long long *snap_mask, const float *noise_rows, const float2 *table, short *out,
+                   float *precast)
 {
     if (n_blocks <= 0) return 0;
-#define JDSP_DN(M, KK) launch_dn<M, KK>(s, pcm, n_blocks, calls_before, st_in, st_out, ver, noise_rows, table, out, precast)
+#define JDSP_DN(M, KK) launch_dn<M, KK>(s, pcm, n_blocks, calls_before, st_in, st_out, ver_base, snap_mask, noise_rows, table, out, precast)
     if (mode == 0) {
         switch (k_opt) {
         case 1: JDSP_DN(0, 1); break;

@@ -77,13 +77,15 @@ void fill_c2c_twiddles(double2 *t, int n_fft);
 int launch_vad(hipStream_t s, const short *pcm, long n_blocks, const double *w_hi, unsigned char *flags,
                long long *dbg_energy, int *dbg_zcr);
 int launch_denoise_plan(hipStream_t s, const unsigned char *flags, long n_blocks, const DenoiseState *st_in,
-                        DenoiseState *st_out, int *nrun, int *ver, int *events, DenoisePlan *plan);
+                        DenoiseState *st_out, int *ver_base, unsigned long long *snap_mask, int *events, int *ev_n,
+                        DenoisePlan *plan);
 int launch_noise_estimate(hipStream_t s, const short *pcm, long n_blocks, const DenoiseState *st_in,
-                          DenoiseState *st_out, const int *events, const int *nrun, const DenoisePlan *plan,
+                          DenoiseState *st_out, const int *events, const int *ev_n, const DenoisePlan *plan,
                           const float2 *table, float *mag, float *noise_rows);
 int launch_denoise(hipStream_t s, int mode, int k_opt, const short *pcm, long n_blocks, long calls_before,
-                   const DenoiseState *st_in, DenoiseState *st_out, const int *ver, const float *noise_rows,
-                   const float2 *table, short *out, float *precast);
+                   const DenoiseState *st_in, DenoiseState *st_out, const int *ver_base,
+                   const unsigned long long *snap_mask, const float *noise_rows, const float2 *table, short *out,
+                   float *precast);
 int ensure_stft1024_table(jdsp_ctx *ctx);
 int ensure_vad_window(jdsp_ctx *ctx);
 // fastconv_kernels.hip
@@ -119,7 +121,8 @@ struct jdsp_denoise {
     double *w_hi = nullptr;               // second half of the FP64 Hamming window (VAD)
     long cap_blocks = 0;                  // workspace capacity
     unsigned char *flags = nullptr;
-    int *nrun = nullptr, *ver = nullptr, *events = nullptr;
+    int *ev_n = nullptr, *ver_base = nullptr, *events = nullptr;
+    unsigned long long *snap_mask = nullptr;
     long long *dbg_energy = nullptr;
     int *dbg_zcr = nullptr;
     jdsp::DenoisePlan *plan = nullptr;

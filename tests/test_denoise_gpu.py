@@ -64,6 +64,21 @@ def test_denoise_stream_matches_oracle(eng, oracle, mode, n_blocks):
     d.close()
 
 
+def test_long_stream_crosses_plan_tiles(eng, oracle):
+    """> 65,536 blocks: the run-length plan walks the batch in tiles and carries its counters."""
+    n_blocks = 66000
+    pcm = speechlike(42, n_blocks, pattern=[12, 9, 3, 4, 15, 7, 1, 2, 11, 30, 64, 100, 10, 5])
+    o_out, o_pre, flags, noises, ver = oracle.denoise_trace(1, pcm)
+    d = eng.denoiser(1)
+    out, pre = d.process(pcm, want_precast=True)
+    check_stream(out, pre, o_out, o_pre)
+    v, _, _ = d.vad_trace(n_blocks)
+    assert np.array_equal(v.astype(np.int32), flags)
+    assert noises.shape[0] > 100                       # many latches, on both sides of the tile boundary
+    assert np.abs(d.noise() - noises[-1]).max() <= TOL * noises[-1].max()
+    d.close()
+
+
 def test_vad_energy_and_zcr_bit_exact(eng, oracle):
     pcm = speechlike(7, 64, pattern=[3, 2, 5, 1])
     d = eng.denoiser(0)
