@@ -170,6 +170,17 @@ int jdsp_fastconv_process_dev(jdsp_fastconv *h, const int16_t *pcm_dev, long n_b
 int jdsp_fastconv_process(jdsp_fastconv *h, const int16_t *pcm_host, long n_blocks, int16_t *out_host,
                           float *precast_host, long *n_out_blocks);
 
+/* ---- FFT autocorrelation pitch --------------------------------------------------- */
+/* PitchEstimation_method1.cpp: CalcPitch (:69-116) for n_blocks blocks of 512 samples.
+ * Frame b = [block b-1, block b] with no window; block -1 is prev_block (NULL: zeros, the
+ * reference's initial keep buffer, :74).  arg[b] = the lag the reference prints as
+ * "Estimation arg" (:109; pitch = 16000/arg), rmax[b] = the autocorrelation there;
+ * autocorr (may be NULL) = r[0..511] per block (:95-97).  pcm must be 16-byte aligned. */
+int jdsp_pitch_autocorr_dev(jdsp_ctx *ctx, const int16_t *pcm_dev, long n_blocks, const int16_t *prev_block_dev,
+                            int32_t *arg_dev, float *rmax_dev, float *autocorr_dev);
+int jdsp_pitch_autocorr(jdsp_ctx *ctx, const int16_t *pcm_host, long n_blocks, const int16_t *prev_block_host,
+                        int32_t *arg_host, float *rmax_host, float *autocorr_host);
+
 /* ---- MFCC ---------------------------------------------------------------------- */
 /* MFCCFeatureExtraction_auto_version1.cpp.  The #defines at :23-33 become a runtime
  * configuration; jdsp_mfcc_native_cfg() fills in the reference's values

@@ -82,6 +82,8 @@ def _load():
         "jdsp_fastconv_process": (i, [vp, vp, l, vp, vp, C.POINTER(l)]),
         "jdsp_vad_blocks": (i, [vp, vp, l, vp, vp, vp]),
         "jdsp_denoise_apply": (i, [vp, vp, l, vp, vp, vp, C.POINTER(l)]),
+        "jdsp_pitch_autocorr_dev": (i, [vp, vp, l, vp, vp, vp, vp]),
+        "jdsp_pitch_autocorr": (i, [vp, vp, l, vp, vp, vp, vp]),
         "jdsp_stft_i16_dev": (i, [vp, vp, l, i, i, vp]),
         "jdsp_stft_i16": (i, [vp, vp, l, i, i, vp, C.POINTER(l)]),
     }

@@ -57,6 +57,12 @@ int main(int argc, char **argv)
             if (MFCCFeatureExtraction(&pcm[b], feat))
                 for (int i = 0; i < 2; i++)
                     if (!(it == 0 && i == 0)) fwrite(feat[i], 8, 12, out);          // MFCC:94-101
+    } else if (!strcmp(what, "pitch")) {
+        for (size_t b = 0; b + 512 <= pcm.size(); b += 512) {
+            CalcPitch(&pcm[b], 512);
+            int a = JeicybooLastPitchArg();
+            fwrite(&a, 4, 1, out);
+        }
     } else if (!strcmp(what, "fft")) {
         std::vector<COMPLEX> a(512), b(512);
         short bits[512];

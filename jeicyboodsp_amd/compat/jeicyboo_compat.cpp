@@ -21,6 +21,10 @@ double g_avg[1024];
 short g_est_keep[512];
 // MFCCFeatureExtraction's static (MFCC:198)
 short g_mfcc_keep[512];
+// CalcPitch's static keep buffer (Pitch1:74) and last result
+short g_pitch_keep[512];
+int g_pitch_arg = 0;
+double g_pitch_max = 0;
 
 [[noreturn]] void die(const char *what, jdsp_ctx *ctx)
 {
@@ -65,6 +69,7 @@ void JeicybooResetStreams(void)
     memset(g_avg, 0, sizeof(g_avg));
     memset(g_est_keep, 0, sizeof(g_est_keep));
     memset(g_mfcc_keep, 0, sizeof(g_mfcc_keep));
+    memset(g_pitch_keep, 0, sizeof(g_pitch_keep));
 }
 
 // ---- FFTAlgorithm_ver2.cpp ----------------------------------------------------------------
@@ -184,3 +189,18 @@ bool MFCCFeatureExtraction(short *in, double (*feat)[12])
     memcpy(g_mfcc_keep, in + 512, sizeof(g_mfcc_keep));           // :228
     return true;
 }
+
+// ---- PitchEstimation_method1.cpp ------------------------------------------------------------
+void CalcPitch(short *in, int n)
+{
+    if (n != 512) { fprintf(stderr, "CalcPitch: iFrameCount must be 512\n"); abort(); }
+    int32_t arg = 0;
+    float rmax = 0;
+    CK(jdsp_pitch_autocorr(JeicybooContext(), in, 1, g_pitch_keep, &arg, &rmax, nullptr));
+    g_pitch_arg = arg;
+    g_pitch_max = rmax;
+    printf("Estimation arg %d , dMin %f pitch %f \n", arg, (double)rmax, (16000.0 / (double)arg));   // :109
+    memcpy(g_pitch_keep, in, sizeof(g_pitch_keep));                                                   // :112
+}
+int JeicybooLastPitchArg(void) { return g_pitch_arg; }
+double JeicybooLastPitchMax(void) { return g_pitch_max; }

@@ -52,4 +52,11 @@ bool MFCCFeatureExtraction(short *rgsInputBuffer, double (*dMFCCFeature)[12]);  
 // MelFilterBank (:154), DCT (:176) and Liftering (:185) are fused into MFCCFeatureExtraction's
 // kernel and are not exported separately.
 
+// ---- PitchEstimation_method1.cpp:31 --------------------------------------------------------
+// Prints the reference's "Estimation arg %d , dMin %f pitch %f" line (:109); the lag and the
+// autocorrelation value of the last call are also available programmatically.
+void CalcPitch(short *psInputBuffer, int iFrameCount);                                          // :69
+int JeicybooLastPitchArg(void);
+double JeicybooLastPitchMax(void);
+
 #endif

@@ -246,6 +246,61 @@ int jdsp_fft_process_f64(jdsp_ctx *ctx, const double *in_host, double *out_host,
     return rc;
 }
 
+/* ---- PitchEstimation_method1 -------------------------------------------------- */
+int jdsp_pitch_autocorr_dev(jdsp_ctx *ctx, const int16_t *pcm_dev, long n_blocks, const int16_t *prev_block_dev,
+                            int32_t *arg_dev, float *rmax_dev, float *autocorr_dev)
+{
+    if (!ctx) return JDSP_EINVAL;
+    if (n_blocks < 0 || (n_blocks > 0 && (!pcm_dev || !arg_dev || !rmax_dev)))
+        return fail(ctx, JDSP_EINVAL, "jdsp_pitch_autocorr: bad buffer");
+    if (n_blocks == 0) return JDSP_OK;
+    if (((uintptr_t)pcm_dev & 15u) || ((uintptr_t)prev_block_dev & 15u))
+        return fail(ctx, JDSP_EINVAL, "jdsp_pitch_autocorr: pcm must be 16-byte aligned");
+    JDSP_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = jdsp::ensure_stft1024_table(ctx);
+    if (rc) return rc;
+    if (jdsp::launch_pitch(ctx->stream, pcm_dev, n_blocks, prev_block_dev, ctx->stft1024_table, arg_dev, rmax_dev,
+                           autocorr_dev))
+        return fail(ctx, JDSP_EHIP, "pitch launch", hipGetLastError());
+    return JDSP_OK;
+}
+
+int jdsp_pitch_autocorr(jdsp_ctx *ctx, const int16_t *pcm_host, long n_blocks, const int16_t *prev_block_host,
+                        int32_t *arg_host, float *rmax_host, float *autocorr_host)
+{
+    if (!ctx) return JDSP_EINVAL;
+    if (n_blocks < 0 || (n_blocks > 0 && (!pcm_host || !arg_host || !rmax_host)))
+        return fail(ctx, JDSP_EINVAL, "jdsp_pitch_autocorr: bad buffer");
+    if (n_blocks == 0) return JDSP_OK;
+    JDSP_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t n = (size_t)n_blocks;
+    int16_t *d_in = nullptr, *d_prev = nullptr;
+    int32_t *d_arg = nullptr;
+    float *d_max = nullptr, *d_ac = nullptr;
+    hipError_t e = hipMalloc((void **)&d_in, n * 1024);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_arg, n * 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_max, n * 4);
+    if (e == hipSuccess && prev_block_host) e = hipMalloc((void **)&d_prev, 1024);
+    if (e == hipSuccess && autocorr_host) e = hipMalloc((void **)&d_ac, n * 2048);
+    hipStream_t s = ctx->stream;
+    int rc = JDSP_OK;
+    if (e == hipSuccess) e = hipMemcpyAsync(d_in, pcm_host, n * 1024, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess && prev_block_host) e = hipMemcpyAsync(d_prev, prev_block_host, 1024, hipMemcpyHostToDevice, s);
+    if (e != hipSuccess) rc = fail(ctx, JDSP_EHIP, "jdsp_pitch_autocorr: staging", e);
+    if (!rc) rc = jdsp_pitch_autocorr_dev(ctx, d_in, n_blocks, d_prev, d_arg, d_max, d_ac);
+    if (!rc && (e = hipMemcpyAsync(arg_host, d_arg, n * 4, hipMemcpyDeviceToHost, s)) != hipSuccess) rc = fail(ctx, JDSP_EHIP, "jdsp_pitch_autocorr: D2H", e);
+    if (!rc && (e = hipMemcpyAsync(rmax_host, d_max, n * 4, hipMemcpyDeviceToHost, s)) != hipSuccess) rc = fail(ctx, JDSP_EHIP, "jdsp_pitch_autocorr: D2H", e);
+    if (!rc && autocorr_host && (e = hipMemcpyAsync(autocorr_host, d_ac, n * 2048, hipMemcpyDeviceToHost, s)) != hipSuccess)
+        rc = fail(ctx, JDSP_EHIP, "jdsp_pitch_autocorr: D2H", e);
+    if ((e = hipStreamSynchronize(s)) != hipSuccess && !rc) rc = fail(ctx, JDSP_EHIP, "jdsp_pitch_autocorr: sync", e);
+    if (d_in) (void)hipFree(d_in);
+    if (d_prev) (void)hipFree(d_prev);
+    if (d_arg) (void)hipFree(d_arg);
+    if (d_max) (void)hipFree(d_max);
+    if (d_ac) (void)hipFree(d_ac);
+    return rc;
+}
+
 /* ---- STFT ------------------------------------------------------------------ */
 int jdsp_stft_i16_dev(jdsp_ctx *ctx, const int16_t *pcm_dev, long n_frames, int n_fft, int hop, jdsp_c32 *spec_dev)
 {

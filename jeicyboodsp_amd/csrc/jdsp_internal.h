@@ -106,6 +106,9 @@ int launch_fastconv(hipStream_t st, int n_fft, const ConvStream &s, long n_out_b
                     int n_taps, int n_filters, const float2 *H, const float2 *table, const float2 *tw4096,
                     const float2 *tw8192, short *out, float *precast, long plane, short *hist_out);
 void fill_conv_twiddles(float2 *tw4096, float2 *tw8192);
+// pitch_kernels.hip
+int launch_pitch(hipStream_t s, const short *pcm, long n_blocks, const short *prev_block, const float2 *table, int *arg,
+                 float *rmax, float *autocorr);
 // mfcc_kernels.hip
 int launch_mfcc(hipStream_t s, const short *pcm, const long long *starts, long n_frames, const MfccDev &p,
                 const float2 *table, double *feats);

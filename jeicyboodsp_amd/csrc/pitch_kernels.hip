@@ -1,0 +1,106 @@
+// pitch_kernels.hip -- PitchEstimation_method1.cpp:69-116 (CalcPitch) on gfx950, one block per
+// wavefront: frame = [previous block, block] (no window) -> forward transform -> |X|^2 ->
+// inverse transform -> autocorrelation r[0..511] -> arg max over lags 511 .. 101.
+#include "frame_io.h"
+#include "jdsp_internal.h"
+
+namespace jdsp {
+
+template <int J>
+__device__ __forceinline__ void power_presplit_j(const float2 *lds, float2 *zout, int lane, const float2 *wsp)
+{
+    const int m = 128 * J + 2 * lane;
+    const float4 zz = *reinterpret_cast<const float4 *>(&lds[m]);
+    const float2 zr0 = lds[(512 - m) & 511];
+    const float2 zr1 = lds[511 - m];
+    float2 lo0, hi0, lo1, hi1;
+    split_fwd<J>(make_float2(zz.x, zz.y), zr0, wsp[0], lo0, hi0);
+    split_fwd<J>(make_float2(zz.z, zz.w), zr1, wsp[1], lo1, hi1);
+    // :91-92  |X|^2 + 0j
+    const float2 pl0 = make_float2(lo0.x * lo0.x + lo0.y * lo0.y, 0.f), ph0 = make_float2(hi0.x * hi0.x + hi0.y * hi0.y, 0.f);
+    const float2 pl1 = make_float2(lo1.x * lo1.x + lo1.y * lo1.y, 0.f), ph1 = make_float2(hi1.x * hi1.x + hi1.y * hi1.y, 0.f);
+    zout[2 * J] = presplit_inv<J>(pl0, ph0, wsp[0]);
+    zout[2 * J + 1] = presplit_inv<J>(pl1, ph1, wsp[1]);
+}
+
+__global__ __launch_bounds__(64) void pitch_autocorr_kernel(const short *__restrict__ pcm, long n_blocks,
+                                                            const short *__restrict__ prev_block,
+                                                            const float2 *__restrict__ table, int *__restrict__ arg,
+                                                            float *__restrict__ rmax, float *__restrict__ autocorr)
+{
+    __shared__ __attribute__((aligned(16))) float2 lds[kWaveLdsComplex];
+    __shared__ __attribute__((aligned(16))) unsigned int stage[256];
+    const int lane = threadIdx.x;
+    const long per_xcd = (gridDim.x + 7) >> 3;
+    const long b = (long)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (b >= n_blocks) return;
+    u32x4 h0 = {0u, 0u, 0u, 0u};                                         // rgssKeepBuffer (:74,:79-81)
+    if (b > 0) h0 = reinterpret_cast<const u32x4 *>(pcm + (b - 1) * 512)[lane];
+    else if (prev_block) h0 = reinterpret_cast<const u32x4 *>(prev_block)[lane];
+    const u32x4 h1 = reinterpret_cast<const u32x4 *>(pcm + b * 512)[lane];
+    WaveTwiddles tw;
+    load_wave_twiddles(tw, table, lane);
+    const float2 wsp[2] = {table[kStftSplit + 2 * lane], table[kStftSplit + 2 * lane + 1]};
+    unsigned int raw[8];
+    relayout_half(stage, lane, h0, raw);
+    relayout_half(stage, lane, h1, raw + 4);
+    float2 v[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const float2 s = unpack_i16x2(raw[r]);
+        v[r] = make_float2(0.5f * s.x, 0.5f * s.y);                     // 0.5: the split's convention (frame_io.h)
+    }
+    wave_fft512<false>(v, lds, lane, tw);
+#pragma unroll
+    for (int d = 0; d < 8; d++) lds[lane + 64 * d] = v[d];
+    wave_lds_fence();
+    float2 z[8];
+    power_presplit_j<0>(lds, z, lane, wsp);
+    power_presplit_j<1>(lds, z, lane, wsp);
+    power_presplit_j<2>(lds, z, lane, wsp);
+    power_presplit_j<3>(lds, z, lane, wsp);
+    wave_lds_fence();
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+        *reinterpret_cast<float4 *>(&lds[128 * j + 2 * lane]) = make_float4(z[2 * j].x, z[2 * j].y, z[2 * j + 1].x, z[2 * j + 1].y);
+    wave_lds_fence();
+    float2 y[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) y[r] = lds[lane + 64 * r];
+    wave_lds_fence();
+    wave_fft512<true>(y, lds, lane, tw);
+    // y[d] = (r[2 lane + 128 d], r[2 lane + 128 d + 1]) * 1024 ; lags 0..511 are d = 0..3 (:95-97)
+    float best = -INFINITY;
+    int at = 0x7fffffff;
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+        const int i0 = 2 * lane + 128 * d;
+        const float a = y[d].x * (1.0f / 1024.0f), c = y[d].y * (1.0f / 1024.0f);
+        if (autocorr) *reinterpret_cast<float2 *>(autocorr + b * 512 + i0) = make_float2(a, c);
+        // :102-108 scans 511 -> 101 with >=: the largest value wins, ties go to the SMALLEST lag
+        if (i0 > 100 && (a > best || (a == best && i0 < at))) { best = a; at = i0; }
+        if (i0 + 1 > 100 && (c > best || (c == best && i0 + 1 < at))) { best = c; at = i0 + 1; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o);
+        const int oa = __shfl_xor(at, o);
+        if (ob > best || (ob == best && oa < at)) { best = ob; at = oa; }
+    }
+    if (lane == 0) {
+        arg[b] = at;
+        rmax[b] = best;
+    }
+}
+
+int launch_pitch(hipStream_t s, const short *pcm, long n_blocks, const short *prev_block, const float2 *table, int *arg,
+                 float *rmax, float *autocorr)
+{
+    if (n_blocks <= 0) return 0;
+    const long grid = (n_blocks + 7) / 8 * 8;
+    hipLaunchKernelGGL(pitch_autocorr_kernel, dim3((unsigned)grid), dim3(64), 0, s, pcm, n_blocks, prev_block, table,
+                       arg, rmax, autocorr);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+}  // namespace jdsp

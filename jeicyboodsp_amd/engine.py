@@ -93,6 +93,36 @@ class Engine:
                                         x.size // n, int(forward)))
         return out
 
+    # ---- PitchEstimation_method1.cpp ---------------------------------------------
+    def pitch(self, pcm, prev_block=None, want_autocorr=False):
+        """CalcPitch (PitchEstimation_method1.cpp:69-116) for every 512-sample block of pcm:
+        returns (arg int32[nb], rmax float32[nb][, autocorr float32[nb,512]])."""
+        if _is_torch(pcm):
+            import torch
+            assert pcm.is_cuda and pcm.dtype == torch.int16 and pcm.is_contiguous() and pcm.numel() % 512 == 0
+            nb = pcm.numel() // 512
+            arg = torch.empty(nb, dtype=torch.int32, device=pcm.device)
+            rmax = torch.empty(nb, dtype=torch.float32, device=pcm.device)
+            ac = torch.empty((nb, 512), dtype=torch.float32, device=pcm.device) if want_autocorr else None
+            self._use_torch_stream()
+            self._ck(L.jdsp_pitch_autocorr_dev(self._h, C.c_void_p(pcm.data_ptr()), nb,
+                                               C.c_void_p(prev_block.data_ptr()) if prev_block is not None else None,
+                                               C.c_void_p(arg.data_ptr()), C.c_void_p(rmax.data_ptr()),
+                                               C.c_void_p(ac.data_ptr()) if want_autocorr else None))
+            return (arg, rmax, ac) if want_autocorr else (arg, rmax)
+        pcm = np.ascontiguousarray(pcm, np.int16)
+        assert pcm.size % 512 == 0
+        nb = pcm.size // 512
+        arg = np.zeros(nb, np.int32)
+        rmax = np.zeros(nb, np.float32)
+        ac = np.zeros((nb, 512), np.float32) if want_autocorr else None
+        pb = np.ascontiguousarray(prev_block, np.int16) if prev_block is not None else None
+        self._ck(L.jdsp_pitch_autocorr(self._h, pcm.ctypes.data_as(C.c_void_p), nb,
+                                       pb.ctypes.data_as(C.c_void_p) if pb is not None else None,
+                                       arg.ctypes.data_as(C.c_void_p), rmax.ctypes.data_as(C.c_void_p),
+                                       ac.ctypes.data_as(C.c_void_p) if want_autocorr else None))
+        return (arg, rmax, ac) if want_autocorr else (arg, rmax)
+
     # ---- STFT analysis (SS:218-230 / WF:181-193 for a whole batch) ---------
     def stft(self, pcm, n_frames=None, n_fft=1024, hop=512, out=None):
         """pcm: int16 numpy array (host path) or torch CUDA int16 tensor (device path).

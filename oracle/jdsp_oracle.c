@@ -487,3 +487,35 @@ long orc_mfcc_stream(const orc_mfcc_cfg *c, const short *pcm, long n_blocks, dou
     free(fi); free(fb); free(mel); free(padded);
     return n_out;
 }
+
+/* ------------------------------------------------------------------------- */
+/* PitchEstimation_method1.cpp:69-116 */
+void orc_pitch_stream(const short *pcm, long n_blocks, int *arg, double *rmax, double *autocorr)
+{
+    orc_cplx *x = (orc_cplx *)calloc(1024, sizeof(orc_cplx));
+    orc_cplx *X = (orc_cplx *)calloc(1024, sizeof(orc_cplx));
+    short keep[512] = {0};                                         /* :74 */
+    double r[512];
+    for (long b = 0; b < n_blocks; b++) {
+        const short *in = pcm + (size_t)b * 512;
+        for (int i = 0; i < 512; i++) { x[i].re = keep[i]; x[i].im = 0; }          /* :79-81 */
+        for (int i = 0; i < 512; i++) { x[512 + i].re = in[i]; x[512 + i].im = 0; } /* :82-84 */
+        orc_dft_c2c(x, X, 1024, -1);                                                /* :88 */
+        for (int i = 0; i < 1024; i++) {                                            /* :90-93 */
+            x[i].re = X[i].re * X[i].re + X[i].im * X[i].im;
+            x[i].im = 0;
+        }
+        orc_dft_c2c(x, X, 1024, +1);                                                /* :94 */
+        for (int i = 0; i < 512; i++) r[i] = X[i].re * 1. / 1024;                   /* :95-97 */
+        double best = r[511];                                                       /* :100 */
+        int at = 0;
+        for (int i = 511; i > 100; i--)                                             /* :102-108 */
+            if (r[i] >= best) { at = i; best = r[i]; }
+        arg[b] = at;
+        rmax[b] = best;
+        if (autocorr) memcpy(autocorr + (size_t)b * 512, r, sizeof(r));
+        memcpy(keep, in, sizeof(keep));                                             /* :112 */
+    }
+    free(x);
+    free(X);
+}

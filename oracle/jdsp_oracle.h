@@ -105,6 +105,12 @@ void orc_mfcc_frame(const orc_mfcc_cfg *c, const int *fi_bins, const double *fba
  * Only valid for win_len == 2*hop.  Returns vectors written. */
 long orc_mfcc_stream(const orc_mfcc_cfg *c, const short *pcm, long n_blocks, double *feats);
 
+/* PitchEstimation_method1.cpp:69-116 CalcPitch for a whole stream of 512-sample blocks
+ * (SURVEY §8f rank 2): frame = [previous block (zeros first), block], no window;
+ * r = IDFT(|DFT(frame)|^2).re / 1024; scan i = 511 .. 101 with `>=` (ties: smallest lag wins).
+ * arg[b], rmax[b] per block; autocorr (may be NULL) gets r[0..511] per block. */
+void orc_pitch_stream(const short *pcm, long n_blocks, int *arg, double *rmax, double *autocorr);
+
 #ifdef __cplusplus
 }
 #endif

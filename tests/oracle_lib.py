@@ -63,6 +63,7 @@ class Oracle:
         L.orc_fastconv_stream.argtypes = [_c_short_p, C.c_long, _c_double_p, C.c_int, C.c_int,
                                           _c_short_p, _c_double_p]
         L.orc_fastconv_stream.restype = C.c_long
+        L.orc_pitch_stream.argtypes = [_c_short_p, C.c_long, _c_int_p, _c_double_p, _c_double_p]
         L.orc_mfcc_native_cfg.argtypes = [C.POINTER(MfccCfg)]
         L.orc_mel_init.argtypes = [C.POINTER(MfccCfg), _c_double_p, _c_int_p, _c_double_p]
         L.orc_mfcc_frame.argtypes = [C.POINTER(MfccCfg), _c_int_p, _c_double_p, _c_short_p, _c_double_p]
@@ -177,6 +178,15 @@ class Oracle:
         n = self.lib.orc_fastconv_stream(_p(pcm, _c_short_p), nb, _p(taps, _c_double_p), taps.size, n_fft,
                                          _p(out, _c_short_p), _p(pre, _c_double_p))
         return out[:n * block].copy(), pre[:n * block].copy()
+
+    def pitch_stream(self, pcm):
+        pcm = np.ascontiguousarray(pcm, np.int16)
+        nb = pcm.size // 512
+        arg = np.zeros(nb, np.int32)
+        rmax = np.zeros(nb, np.float64)
+        ac = np.zeros((nb, 512), np.float64)
+        self.lib.orc_pitch_stream(_p(pcm, _c_short_p), nb, _p(arg, _c_int_p), _p(rmax, _c_double_p), _p(ac, _c_double_p))
+        return arg, rmax, ac
 
     def mfcc_native_cfg(self):
         c = MfccCfg()
