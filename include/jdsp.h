@@ -181,6 +181,27 @@ int jdsp_pitch_autocorr_dev(jdsp_ctx *ctx, const int16_t *pcm_dev, long n_blocks
 int jdsp_pitch_autocorr(jdsp_ctx *ctx, const int16_t *pcm_host, long n_blocks, const int16_t *prev_block_host,
                         int32_t *arg_host, float *rmax_host, float *autocorr_host);
 
+/* ---- two-microphone MVDR beamformer ----------------------------------------------- */
+/* BeamForming_MVDR_ver1.cpp.  One jdsp_mvdr object = the statics of one stereo stream
+ * (rgdSpatialCorr :57, the run counter :59, the keep/temp buffers :56,:130-131, iNumOfCount
+ * :137).  d_time is ProcessMVDR's dTime (:124; the reference's main() passes
+ * (DISTANCE_OF_MIC/SPEED_OF_SOUND)*sin(0) = 0, :60,:121).  jdsp_mvdr_process* replaces, for
+ * n_blocks blocks of 512 samples per channel, one iteration each of main()'s loop (:169-231):
+ * VoiceActivityDetection on the left channel (:207-242), EstimateSpatialCorrMtx (:244-270) and
+ * ProcessMVDR (:124-205).  The first block of a stream produces no output (:201-204); until the
+ * correlation matrix is invertible the reference's samples are NaN, cast to 0 here.
+ * jdsp_mvdr_corr: current rgdSpatialCorr, row-major (4 doubles, host; synchronises). */
+typedef struct jdsp_mvdr jdsp_mvdr;
+int jdsp_mvdr_create(jdsp_ctx *ctx, double d_time, jdsp_mvdr **out);
+int jdsp_mvdr_destroy(jdsp_mvdr *h);
+int jdsp_mvdr_reset(jdsp_mvdr *h);
+long jdsp_mvdr_blocks_out(const jdsp_mvdr *h, long n_blocks);
+int jdsp_mvdr_process_dev(jdsp_mvdr *h, const int16_t *left_dev, const int16_t *right_dev, long n_blocks,
+                          int16_t *out_dev, float *precast_dev, long *n_out_blocks);
+int jdsp_mvdr_process(jdsp_mvdr *h, const int16_t *left_host, const int16_t *right_host, long n_blocks,
+                      int16_t *out_host, float *precast_host, long *n_out_blocks);
+int jdsp_mvdr_corr(jdsp_mvdr *h, double *corr4_host);
+
 /* ---- MFCC ---------------------------------------------------------------------- */
 /* MFCCFeatureExtraction_auto_version1.cpp.  The #defines at :23-33 become a runtime
  * configuration; jdsp_mfcc_native_cfg() fills in the reference's values

@@ -84,6 +84,13 @@ def _load():
         "jdsp_denoise_apply": (i, [vp, vp, l, vp, vp, vp, C.POINTER(l)]),
         "jdsp_pitch_autocorr_dev": (i, [vp, vp, l, vp, vp, vp, vp]),
         "jdsp_pitch_autocorr": (i, [vp, vp, l, vp, vp, vp, vp]),
+        "jdsp_mvdr_create": (i, [vp, C.c_double, C.POINTER(vp)]),
+        "jdsp_mvdr_destroy": (i, [vp]),
+        "jdsp_mvdr_reset": (i, [vp]),
+        "jdsp_mvdr_blocks_out": (l, [vp, l]),
+        "jdsp_mvdr_process_dev": (i, [vp, vp, vp, l, vp, vp, C.POINTER(l)]),
+        "jdsp_mvdr_process": (i, [vp, vp, vp, l, vp, vp, C.POINTER(l)]),
+        "jdsp_mvdr_corr": (i, [vp, vp]),
         "jdsp_stft_i16_dev": (i, [vp, vp, l, i, i, vp]),
         "jdsp_stft_i16": (i, [vp, vp, l, i, i, vp, C.POINTER(l)]),
     }

@@ -1,6 +1,6 @@
 // drivers.cpp -- the reference programs' command lines over the BATCHED C ABI: each program
 // reads its whole input like the reference's fread() loop would, makes ONE engine call per
-// stream and writes the reference's output format.  Built as five executables (Makefile):
+// stream and writes the reference's output format.  Built as seven executables (Makefile):
 //
 //   jdsp_fftalg   in.wav  out.raw            FFTAlgorithm_ver2.cpp main()            (:30-92)
 //   jdsp_specsub  in.raw  out.raw            SpectralSubtraction_final.cpp main()    (:62-119)
@@ -9,11 +9,14 @@
 //                                            taps.f64 = raw little-endian doubles (the reference
 //                                            compiles FilterCoefficient.h in; n_taps = size/8)
 //   jdsp_mfcc     list.txt                   MFCCFeatureExtraction_auto_version1.cpp main() (:44-114)
+//   jdsp_mvdr     left.wav right.wav out.raw BeamForming_MVDR_ver1.cpp main()        (:47-122)
+//   jdsp_pitch1   in.wav                     PitchEstimation_method1.cpp main()      (:33-67); prints like :109
 //
 // File conventions kept from the reference: raw little-endian int16 PCM; a 44-byte WAV header
 // is skipped by fftalg/conv3d/mfcc (FFT:59, 3D:79, MFCC:83) and NOT by specsub/wiener
 // (SS:89, WF:81 commented out); a short final fread() is processed with the stale tail of the
 // previous block still in the buffer (e.g. SS:94: the loop only stops when fread returns 0).
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -149,6 +152,40 @@ static int run_mfcc(int argc, char **argv)
     return 0;
 }
 
+static int run_mvdr(int argc, char **argv)
+{
+    if (argc != 4) { fprintf(stderr, "usage: jdsp_mvdr left.wav right.wav out.raw\n"); return 1; }
+    FILE *fl = open_or_die(argv[1], "rb"), *fr = open_or_die(argv[2], "rb"), *out = open_or_die(argv[3], "wb");
+    std::vector<short> l = read_blocks(fl, 512, 44), r = read_blocks(fr, 512, 44);      // :80-81,:85-93
+    const long nb = (long)std::min(l.size(), r.size()) / 512;                           // the loop stops at the shorter file
+    jdsp_mvdr *h = nullptr;
+    CK(jdsp_mvdr_create(g_ctx, 0.0, &h));                                               // dAngle = 0 (:60)
+    std::vector<short> res((size_t)(nb > 0 ? nb : 1) * 512);
+    long n_out = 0;
+    CK(jdsp_mvdr_process(h, l.data(), r.data(), nb, res.data(), nullptr, &n_out));
+    fwrite(res.data(), sizeof(short), (size_t)n_out * 512, out);
+    jdsp_mvdr_destroy(h);
+    fclose(fl); fclose(fr); fclose(out);
+    printf("Processing End\n");
+    return 0;
+}
+
+static int run_pitch1(int argc, char **argv)
+{
+    if (argc != 2) { fprintf(stderr, "usage: jdsp_pitch1 in.wav\n"); return 1; }
+    FILE *in = open_or_die(argv[1], "rb");
+    std::vector<short> pcm = read_blocks(in, 512, 44);                                  // :53,:57
+    const long nb = (long)pcm.size() / 512;
+    std::vector<int32_t> arg((size_t)(nb > 0 ? nb : 1));
+    std::vector<float> rmax((size_t)(nb > 0 ? nb : 1));
+    CK(jdsp_pitch_autocorr(g_ctx, pcm.data(), nb, nullptr, arg.data(), rmax.data(), nullptr));
+    for (long b = 0; b < nb; b++)
+        printf("Estimation arg %d , dMin %f pitch %f \n", arg[b], (double)rmax[b], 16000.0 / (double)arg[b]);   // :109
+    fclose(in);
+    printf("Processing End\n");
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
     std::string prog = argv[0];
@@ -162,7 +199,9 @@ int main(int argc, char **argv)
     else if (prog == "jdsp_wiener") rc = run_denoise(JDSP_WIENER, argc, argv);
     else if (prog == "jdsp_conv3d") rc = run_conv3d(argc, argv);
     else if (prog == "jdsp_mfcc") rc = run_mfcc(argc, argv);
-    else fprintf(stderr, "unknown program name %s (expected jdsp_fftalg|jdsp_specsub|jdsp_wiener|jdsp_conv3d|jdsp_mfcc)\n", prog.c_str());
+    else if (prog == "jdsp_mvdr") rc = run_mvdr(argc, argv);
+    else if (prog == "jdsp_pitch1") rc = run_pitch1(argc, argv);
+    else fprintf(stderr, "unknown program name %s (expected jdsp_fftalg|jdsp_specsub|jdsp_wiener|jdsp_conv3d|jdsp_mfcc|jdsp_mvdr|jdsp_pitch1)\n", prog.c_str());
     jdsp_destroy(g_ctx);
     return rc;
 }

@@ -135,7 +135,7 @@ int jdsp_denoise_process_dev(jdsp_denoise *h, const int16_t *pcm_dev, long n_blo
     const jdsp::DenoiseState *st_in = h->st[h->cur];
     jdsp::DenoiseState *st_out = h->st[h->cur ^ 1];
     hipStream_t s = ctx->stream;
-    if (jdsp::launch_vad(s, pcm_dev, n_blocks, h->w_hi, h->flags, h->dbg_energy, h->dbg_zcr) ||
+    if (jdsp::launch_vad(s, pcm_dev, n_blocks, h->w_hi, 1, h->flags, h->dbg_energy, h->dbg_zcr) ||
         jdsp::launch_denoise_plan(s, h->flags, n_blocks, st_in, st_out, h->ver_base, h->snap_mask, h->events, h->ev_n,
                                   h->plan) ||
         jdsp::launch_noise_estimate(s, pcm_dev, n_blocks, st_in, st_out, h->events, h->ev_n, h->plan,
@@ -255,7 +255,7 @@ int jdsp_vad_blocks(jdsp_ctx *ctx, const int16_t *pcm_host, long n_blocks, uint8
     hipStream_t s = ctx->stream;
     if (e == hipSuccess) e = hipMemcpyAsync(d_in, pcm_host, n * 1024, hipMemcpyHostToDevice, s);
     if (e != hipSuccess) rc = fail(ctx, JDSP_EHIP, "jdsp_vad_blocks: staging", e);
-    if (!rc && jdsp::launch_vad(s, d_in, n_blocks, ctx->vad_w_hi, d_v, d_e, d_z)) rc = fail(ctx, JDSP_EHIP, "vad launch", hipGetLastError());
+    if (!rc && jdsp::launch_vad(s, d_in, n_blocks, ctx->vad_w_hi, 1, d_v, d_e, d_z)) rc = fail(ctx, JDSP_EHIP, "vad launch", hipGetLastError());
     if (!rc && voice_host && (e = hipMemcpyAsync(voice_host, d_v, n, hipMemcpyDeviceToHost, s)) != hipSuccess) rc = fail(ctx, JDSP_EHIP, "jdsp_vad_blocks: D2H", e);
     if (!rc && energy_sum_host && (e = hipMemcpyAsync(energy_sum_host, d_e, n * 8, hipMemcpyDeviceToHost, s)) != hipSuccess) rc = fail(ctx, JDSP_EHIP, "jdsp_vad_blocks: D2H", e);
     if (!rc && zcr_host && (e = hipMemcpyAsync(zcr_host, d_z, n * 4, hipMemcpyDeviceToHost, s)) != hipSuccess) rc = fail(ctx, JDSP_EHIP, "jdsp_vad_blocks: D2H", e);

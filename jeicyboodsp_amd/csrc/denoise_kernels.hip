@@ -26,7 +26,8 @@ namespace jdsp {
 // unreachable); s = (short)(x * w) truncates; E = sum s^2 / 1024; Z counts s[i]*x[i+1] < 0
 // (the next sample is not windowed yet, SS:139).  E > 700 <=> sum s^2 > 716800 exactly.
 __global__ __launch_bounds__(64) void vad_kernel(const short *__restrict__ pcm, long n_blocks,
-                                                 const double *__restrict__ w_hi, unsigned char *__restrict__ flags,
+                                                 const double *__restrict__ w_hi, int use_zcr,
+                                                 unsigned char *__restrict__ flags,
                                                  long long *__restrict__ dbg_energy, int *__restrict__ dbg_zcr)
 {
     const long b = blockIdx.x;
@@ -54,7 +55,8 @@ __global__ __launch_bounds__(64) void vad_kernel(const short *__restrict__ pcm, 
         z += __shfl_xor(z, o);
     }
     if (lane == 0) {
-        flags[b] = (e > 716800LL || z < 200) ? 1 : 0;      // SS:147 with THRESHOLD_OF_ENERGY 700, _ZCR 200
+        // SS:147 with THRESHOLD_OF_ENERGY 700, _ZCR 200; BeamForming_MVDR_ver1.cpp:233 tests the energy only
+        flags[b] = (e > 716800LL || (use_zcr && z < 200)) ? 1 : 0;
         if (dbg_energy) dbg_energy[b] = e;
         if (dbg_zcr) dbg_zcr[b] = z;
     }
@@ -81,25 +83,21 @@ __device__ __forceinline__ RunSummary combine(RunSummary a, RunSummary b)
     return r;
 }
 
-__device__ __forceinline__ int version_of(const int *__restrict__ ver_base,
-                                          const unsigned long long *__restrict__ snap_mask, long j)
-{
-    const unsigned long long m = snap_mask[j >> 6] & (~0ull >> (63 - (int)(j & 63)));
-    return ver_base[j >> 6] + __popcll(m);
-}
-
 __global__ __launch_bounds__(1024) void plan_kernel(const unsigned char *__restrict__ flags, long n_blocks,
-                                                    const DenoiseState *__restrict__ st_in, DenoiseState *st_out,
+                                                    const int *__restrict__ run_len_in_p, DenoiseState *st_out,
                                                     int *__restrict__ ver_base,
                                                     unsigned long long *__restrict__ snap_mask,
                                                     int *__restrict__ events, int *__restrict__ ev_n,
-                                                    DenoisePlan *plan)
+                                                    DenoisePlan *plan, int latch_run, int *run_len_out)
 {
+    // latch_run > 0: the estimate changes when the run length equals it (SS:189: 10);
+    // latch_run == 0: it changes at every event (BeamForming_MVDR_ver1.cpp:201 accumulates each time)
     __shared__ RunSummary sum[1024];
     __shared__ int cnt_ev[1024], cnt_sn[1024];
     __shared__ int carry_run, carry_ev, carry_sn;
     const int t = threadIdx.x;
-    if (t == 0) { carry_run = st_in->run_len; carry_ev = 0; carry_sn = 0; }
+    const int run_len_in = *run_len_in_p;
+    if (t == 0) { carry_run = run_len_in; carry_ev = 0; carry_sn = 0; }
     __syncthreads();
 
     for (long tile0 = 0; tile0 < n_blocks; tile0 += 65536) {
@@ -145,7 +143,7 @@ __global__ __launch_bounds__(1024) void plan_kernel(const unsigned char *__restr
             else {
                 r++;
                 if (r >= 2) E |= 1ull << i;
-                if (r == 10) S |= 1ull << i;
+                if (latch_run > 0 ? r == latch_run : r >= 2) S |= 1ull << i;
             }
         }
         const int ne = __popcll(E), ns = __popcll(S);
@@ -184,7 +182,8 @@ __global__ __launch_bounds__(1024) void plan_kernel(const unsigned char *__restr
         __syncthreads();
     }
     if (t == 0) {
-        st_out->run_len = carry_run;
+        if (st_out) st_out->run_len = carry_run;
+        if (run_len_out) *run_len_out = carry_run;
         plan->n_events = carry_ev;
         plan->n_snap = carry_sn;
     }
@@ -442,12 +441,12 @@ __global__ __launch_bounds__(64, JDSP_DENOISE_MINWAVES) void denoise_kernel(
 }
 
 // ---------------------------------------------------------------------------------------
-int launch_vad(hipStream_t s, const short *pcm, long n_blocks, const double *w_hi, unsigned char *flags,
+int launch_vad(hipStream_t s, const short *pcm, long n_blocks, const double *w_hi, int use_zcr, unsigned char *flags,
                long long *dbg_energy, int *dbg_zcr)
 {
     if (n_blocks <= 0) return 0;
-    hipLaunchKernelGGL(vad_kernel, dim3((unsigned)n_blocks), dim3(64), 0, s, pcm, n_blocks, w_hi, flags, dbg_energy,
-                       dbg_zcr);
+    hipLaunchKernelGGL(vad_kernel, dim3((unsigned)n_blocks), dim3(64), 0, s, pcm, n_blocks, w_hi, use_zcr, flags,
+                       dbg_energy, dbg_zcr);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
@@ -455,8 +454,18 @@ int launch_denoise_plan(hipStream_t s, const unsigned char *flags, long n_blocks
                         DenoiseState *st_out, int *ver_base, unsigned long long *snap_mask, int *events, int *ev_n,
                         DenoisePlan *plan)
 {
-    hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(1024), 0, s, flags, n_blocks, st_in, st_out, ver_base, snap_mask,
-                       events, ev_n, plan);
+    hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(1024), 0, s, flags, n_blocks, &st_in->run_len, st_out, ver_base,
+                       snap_mask, events, ev_n, plan, 10, (int *)nullptr);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// the same scan for callers with their own state layout (mvdr_kernels.hip)
+int launch_run_plan(hipStream_t s, const unsigned char *flags, long n_blocks, const int *run_len_in, int *run_len_out,
+                    int latch_run, int *ver_base, unsigned long long *snap_mask, int *events, int *ev_n,
+                    DenoisePlan *plan)
+{
+    hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(1024), 0, s, flags, n_blocks, run_len_in, (DenoiseState *)nullptr,
+                       ver_base, snap_mask, events, ev_n, plan, latch_run, run_len_out);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

@@ -87,4 +87,14 @@ __device__ __forceinline__ void relayout_half(unsigned int *stage, int lane, u32
     wave_lds_fence();
 }
 
+// Which estimate applies to block j, from plan_kernel's per-64-block summaries
+// (denoise_kernels.hip): the count of latches at or before j.
+__device__ __forceinline__ int version_of(const int *__restrict__ ver_base,
+                                          const unsigned long long *__restrict__ snap_mask, long j)
+{
+    const unsigned long long m = snap_mask[j >> 6] & (~0ull >> (63 - (int)(j & 63)));
+    return ver_base[j >> 6] + __popcll(m);
+}
+
+
 }  // namespace jdsp

@@ -40,6 +40,15 @@ struct DenoiseState {
 };
 struct DenoisePlan { int n_events, n_snap, pad0, pad1; };
 
+// BeamForming_MVDR_ver1.cpp's state between calls (device memory)
+struct MvdrState {
+    int run_len;          // main(): iNumOfIteration             MVDR:59,99,108
+    int pad[3];
+    double corr[4];       // rgdSpatialCorr, row-major             MVDR:57
+    short prev_l[512];    // previous block of each channel (temp buffers :56, keep buffers :130-131)
+    short prev_r[512];
+};
+
 // Device-side view of one MFCC configuration (passed by value to the kernel).
 struct MfccDev {
     int win_len, hop, n_chan, n_cep, bin_stride;   // bin_stride 2: 512-point bins out of the 1024-point transform
@@ -74,8 +83,11 @@ void fill_c2c_twiddles(double2 *t, int n_fft);
 
 
 // denoise_kernels.hip
-int launch_vad(hipStream_t s, const short *pcm, long n_blocks, const double *w_hi, unsigned char *flags,
+int launch_vad(hipStream_t s, const short *pcm, long n_blocks, const double *w_hi, int use_zcr, unsigned char *flags,
                long long *dbg_energy, int *dbg_zcr);
+int launch_run_plan(hipStream_t s, const unsigned char *flags, long n_blocks, const int *run_len_in, int *run_len_out,
+                    int latch_run, int *ver_base, unsigned long long *snap_mask, int *events, int *ev_n,
+                    DenoisePlan *plan);
 int launch_denoise_plan(hipStream_t s, const unsigned char *flags, long n_blocks, const DenoiseState *st_in,
                         DenoiseState *st_out, int *ver_base, unsigned long long *snap_mask, int *events, int *ev_n,
                         DenoisePlan *plan);
@@ -106,6 +118,11 @@ int launch_fastconv(hipStream_t st, int n_fft, const ConvStream &s, long n_out_b
                     int n_taps, int n_filters, const float2 *H, const float2 *table, const float2 *tw4096,
                     const float2 *tw8192, short *out, float *precast, long plane, short *hist_out);
 void fill_conv_twiddles(float2 *tw4096, float2 *tw8192);
+// mvdr_kernels.hip
+int launch_mvdr(hipStream_t s, const short *left, const short *right, long n_blocks, long calls_before,
+                const MvdrState *st_in, MvdrState *st_out, const int *events, const DenoisePlan *plan,
+                const int *ver_base, const unsigned long long *snap_mask, double *delta, double *rver,
+                const double2 *steer, const float2 *table, short *out, float *precast);
 // pitch_kernels.hip
 int launch_pitch(hipStream_t s, const short *pcm, long n_blocks, const short *prev_block, const float2 *table, int *arg,
                  float *rmax, float *autocorr);
@@ -150,4 +167,20 @@ struct jdsp_fastconv {
     short *hist[2] = {nullptr, nullptr};  // last n_taps-1 samples of the stream, ping-pong
     int cur = 0;
     long calls = 0;                       // blocks consumed so far (siNumOfCount)
+};
+
+struct jdsp_mvdr {
+    jdsp_ctx *ctx = nullptr;
+    double d_time = 0;
+    long calls = 0;
+    jdsp::MvdrState *st[2] = {nullptr, nullptr};
+    int cur = 0;
+    jdsp::DenoisePlan *plan = nullptr;
+    double2 *steer = nullptr;             // [1024] steering vector's second component per bin
+    double *w_vad = nullptr;              // Hamming[511 .. 1022] in FP64
+    long cap_blocks = 0;
+    unsigned char *flags = nullptr;
+    int *events = nullptr, *ev_n = nullptr, *ver_base = nullptr;
+    unsigned long long *snap_mask = nullptr;
+    double *delta = nullptr, *rver = nullptr;
 };

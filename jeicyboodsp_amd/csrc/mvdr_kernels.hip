@@ -1,0 +1,251 @@
+// mvdr_kernels.hip -- BeamForming_MVDR_ver1.cpp (stretch) on gfx950: two
+// microphones, one real 2x2 "spatial correlation" accumulated over non-voice runs and over ALL
+// bins (:263-268), per-bin weights w = R^-1 c / (c^H R^-1 c) (:170-171), both spectra weighted
+// (with the reference's in-place overwrite, :180-183), summed, inverse-transformed; samples
+// 511..1022 of every frame are emitted (:192-194).
+//
+//   vad_kernel (denoise_kernels.hip)   :207-242 energy-only decision, window offset 511
+//   plan_kernel (denoise_kernels.hip)  main()'s run counter :191-219; every event changes R
+//   mvdr_corr_kernel                   :244-270 per event: the four sums over 1024 bins
+//   mvdr_prefix_kernel                 running R after each event (FP64)
+//   mvdr_kernel                        :124-205 one block per wavefront
+#include "frame_io.h"
+#include "jdsp_internal.h"
+
+namespace jdsp {
+
+__device__ __forceinline__ u32x4 mvdr_load_block(const short *__restrict__ pcm, long n_blocks,
+                                                 const short *__restrict__ prev, long j, int lane)
+{
+    u32x4 zero = {0u, 0u, 0u, 0u};
+    if (j >= 0 && j < n_blocks) return reinterpret_cast<const u32x4 *>(pcm + j * 512)[lane];
+    if (j == -1) return reinterpret_cast<const u32x4 *>(prev)[lane];
+    return zero;
+}
+
+// forward transform of 8 float2 (already scaled by 0.5) -> X[m], X[m+512] for m = 128 j + 2 lane + e
+__device__ __forceinline__ void spectrum_of(float2 (&v)[8], float2 *lds, int lane, const WaveTwiddles &tw,
+                                            const float2 *wsp, float2 (&lo)[8], float2 (&hi)[8])
+{
+    wave_fft512<false>(v, lds, lane, tw);
+#pragma unroll
+    for (int d = 0; d < 8; d++) lds[lane + 64 * d] = v[d];
+    wave_lds_fence();
+#define JDSP_SPLIT(J)                                                                          \
+    {                                                                                          \
+        const int m = 128 * J + 2 * lane;                                                      \
+        const float4 zz = *reinterpret_cast<const float4 *>(&lds[m]);                          \
+        const float2 zr0 = lds[(512 - m) & 511], zr1 = lds[511 - m];                           \
+        split_fwd<J>(make_float2(zz.x, zz.y), zr0, wsp[0], lo[2 * J], hi[2 * J]);             \
+        split_fwd<J>(make_float2(zz.z, zz.w), zr1, wsp[1], lo[2 * J + 1], hi[2 * J + 1]);     \
+    }
+    JDSP_SPLIT(0) JDSP_SPLIT(1) JDSP_SPLIT(2) JDSP_SPLIT(3)
+#undef JDSP_SPLIT
+    wave_lds_fence();
+}
+
+// :244-270 -- frame = [block j-1, block j] of each channel, no window
+__global__ __launch_bounds__(64) void mvdr_corr_kernel(const short *__restrict__ left, const short *__restrict__ right,
+                                                       long n_blocks, const MvdrState *__restrict__ st_in,
+                                                       const int *__restrict__ events,
+                                                       const DenoisePlan *__restrict__ plan,
+                                                       const float2 *__restrict__ table, double *__restrict__ delta)
+{
+    __shared__ __attribute__((aligned(16))) float2 lds[kWaveLdsComplex];
+    __shared__ __attribute__((aligned(16))) unsigned int stage[256];
+    const int lane = threadIdx.x;
+    const int n_events = plan->n_events;
+    if ((int)blockIdx.x >= n_events) return;
+    WaveTwiddles tw;
+    load_wave_twiddles(tw, table, lane);
+    const float2 wsp[2] = {table[kStftSplit + 2 * lane], table[kStftSplit + 2 * lane + 1]};
+    for (int e = blockIdx.x; e < n_events; e += gridDim.x) {
+        const long j = events[e];
+        float2 llo[8], lhi[8], rlo[8], rhi[8], v[8];
+        unsigned int raw[8];
+        relayout_half(stage, lane, mvdr_load_block(left, n_blocks, st_in->prev_l, j - 1, lane), raw);
+        relayout_half(stage, lane, mvdr_load_block(left, n_blocks, st_in->prev_l, j, lane), raw + 4);
+#pragma unroll
+        for (int r = 0; r < 8; r++) { const float2 s = unpack_i16x2(raw[r]); v[r] = make_float2(0.5f * s.x, 0.5f * s.y); }
+        spectrum_of(v, lds, lane, tw, wsp, llo, lhi);
+        relayout_half(stage, lane, mvdr_load_block(right, n_blocks, st_in->prev_r, j - 1, lane), raw);
+        relayout_half(stage, lane, mvdr_load_block(right, n_blocks, st_in->prev_r, j, lane), raw + 4);
+#pragma unroll
+        for (int r = 0; r < 8; r++) { const float2 s = unpack_i16x2(raw[r]); v[r] = make_float2(0.5f * s.x, 0.5f * s.y); }
+        spectrum_of(v, lds, lane, tw, wsp, rlo, rhi);
+        double s00 = 0, s01 = 0, s10 = 0, s11 = 0;
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const float2 L = h ? lhi[q] : llo[q], R = h ? rhi[q] : rlo[q];
+                s00 += (double)(L.x * L.x + L.y * L.y);                 // :264
+                s01 += (double)(-L.x * R.y + L.y * R.x);                // :265
+                s10 += (double)(-R.x * L.y + R.y * L.x);                // :266
+                s11 += (double)(R.x * R.x + R.y * R.y);                 // :267
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            s00 += __shfl_xor(s00, o); s01 += __shfl_xor(s01, o);
+            s10 += __shfl_xor(s10, o); s11 += __shfl_xor(s11, o);
+        }
+        if (lane == 0) {
+            double *d = delta + (size_t)e * 4;
+            d[0] = s00 / 1024.0; d[1] = s01 / 1024.0; d[2] = s10 / 1024.0; d[3] = s11 / 1024.0;
+        }
+    }
+}
+
+// R after event e: rver[e+1] = rver[e] + delta[e]; rver[0] = the matrix carried in.
+__global__ void mvdr_prefix_kernel(const double *__restrict__ delta, const DenoisePlan *__restrict__ plan,
+                                   const MvdrState *__restrict__ st_in, MvdrState *st_out, double *__restrict__ rver)
+{
+    const int c = threadIdx.x;
+    if (c >= 4) return;
+    double acc = st_in->corr[c];
+    rver[c] = acc;
+    const int n = plan->n_events;
+    for (int e = 0; e < n; e++) {
+        acc += delta[(size_t)e * 4 + c];
+        rver[(size_t)(e + 1) * 4 + c] = acc;
+    }
+    st_out->corr[c] = acc;
+}
+
+// frame position p of block j: [first 511 samples of block j-1, block j, 0]  (:136-141,:195-196)
+__device__ __forceinline__ float mvdr_sample(const short *__restrict__ pcm, const short *__restrict__ prev, long j,
+                                             bool have_prev, int p)
+{
+    if (p >= 1023) return 0.f;
+    if (p >= 511) return (float)pcm[j * 512 + (p - 511)];
+    if (!have_prev) return 0.f;                                     // keep buffer of the very first call: zeros
+    return j > 0 ? (float)pcm[(j - 1) * 512 + p] : (float)prev[p];
+}
+
+__global__ __launch_bounds__(64) void mvdr_kernel(const short *__restrict__ left, const short *__restrict__ right,
+                                                  long n_blocks, long calls_before,
+                                                  const MvdrState *__restrict__ st_in, MvdrState *st_out,
+                                                  const int *__restrict__ ver_base,
+                                                  const unsigned long long *__restrict__ snap_mask,
+                                                  const double *__restrict__ rver, const double2 *__restrict__ steer,
+                                                  const float2 *__restrict__ table, short *__restrict__ out,
+                                                  float *__restrict__ precast)
+{
+    __shared__ __attribute__((aligned(16))) float2 lds[kWaveLdsComplex];
+    __shared__ __attribute__((aligned(16))) float2 merged[1024];
+    const int lane = threadIdx.x;
+    const long per_xcd = (gridDim.x + 7) >> 3;
+    const long j = (long)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (j >= n_blocks) return;
+    WaveTwiddles tw;
+    load_wave_twiddles(tw, table, lane);
+    const float2 wsp[2] = {table[kStftSplit + 2 * lane], table[kStftSplit + 2 * lane + 1]};
+    const bool have_prev = calls_before + j > 0;
+
+    float2 llo[8], lhi[8], rlo[8], rhi[8], v[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const int p = 2 * lane + 128 * r;
+        v[r] = make_float2(0.5f * mvdr_sample(left, st_in->prev_l, j, have_prev, p),
+                           0.5f * mvdr_sample(left, st_in->prev_l, j, have_prev, p + 1));
+    }
+    spectrum_of(v, lds, lane, tw, wsp, llo, lhi);
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const int p = 2 * lane + 128 * r;
+        v[r] = make_float2(0.5f * mvdr_sample(right, st_in->prev_r, j, have_prev, p),
+                           0.5f * mvdr_sample(right, st_in->prev_r, j, have_prev, p + 1));
+    }
+    spectrum_of(v, lds, lane, tw, wsp, rlo, rhi);
+
+    // mxAutoCorr.inverse() (:170) for the matrix in effect at this block
+    const double *R = rver + (size_t)version_of(ver_base, snap_mask, j) * 4;
+    const double a = R[0], b = R[1], c = R[2], d = R[3];
+    const double invdet = 1.0 / (a * d - b * c);
+    const double i00 = d * invdet, i01 = -b * invdet, i10 = -c * invdet, i11 = a * invdet;
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int bin = 128 * (q >> 1) + 2 * lane + (q & 1) + 512 * h;
+            const double2 s1 = steer[bin];                            // (cos, sin)(2 PI i fs/N dTime)  :164-165
+            double w0r = i00 + i01 * s1.x, w0i = i01 * s1.y;          // R^-1 c, c = (1, s1)
+            double w1r = i10 + i11 * s1.x, w1i = i11 * s1.y;
+            const double dr = w0r + (s1.x * w1r + s1.y * w1i);        // c^H (R^-1 c)
+            const double di = w0i + (s1.x * w1i - s1.y * w1r);
+            const double dn = dr * dr + di * di;
+            const double t0r = (w0r * dr + w0i * di) / dn, t0i = (w0i * dr - w0r * di) / dn;     // :171
+            const double t1r = (w1r * dr + w1i * di) / dn, t1i = (w1i * dr - w1r * di) / dn;
+            const float lw0 = (float)t0r, lw1 = (float)-t0i, rw0 = (float)t1r, rw1 = (float)-t1i;   // :175-178 conjugates
+            float2 L = h ? lhi[q] : llo[q], Rr = h ? rhi[q] : rlo[q];
+            // :180-183 -- the imaginary part is formed from the ALREADY OVERWRITTEN real part
+            L.x = L.x * lw0 - L.y * lw1;
+            L.y = L.x * lw1 + L.y * lw0;
+            Rr.x = Rr.x * rw0 - Rr.y * rw1;
+            Rr.y = Rr.x * rw1 + Rr.y * rw0;
+            merged[bin] = make_float2(L.x + Rr.x, L.y + Rr.y);        // :184-185
+        }
+    }
+    wave_lds_fence();
+    // The reference keeps only the real part of the inverse transform (:193) = the inverse
+    // transform of the Hermitian part of the merged spectrum.
+    float2 z[8];
+#define JDSP_HERM(J)                                                                                  \
+    {                                                                                                 \
+        _Pragma("unroll") for (int e = 0; e < 2; e++) {                                               \
+            const int m = 128 * J + 2 * lane + e;                                                     \
+            const float2 a0 = merged[m], a1 = merged[(1024 - m) & 1023];                              \
+            const float2 b0 = merged[m + 512], b1 = merged[512 - m];                                  \
+            const float2 ylo = make_float2(0.5f * (a0.x + a1.x), 0.5f * (a0.y - a1.y));               \
+            const float2 yhi = make_float2(0.5f * (b0.x + b1.x), 0.5f * (b0.y - b1.y));               \
+            z[2 * J + e] = presplit_inv<J>(ylo, yhi, wsp[e]);                                         \
+        }                                                                                             \
+    }
+    JDSP_HERM(0) JDSP_HERM(1) JDSP_HERM(2) JDSP_HERM(3)
+#undef JDSP_HERM
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+        *reinterpret_cast<float4 *>(&lds[128 * q + 2 * lane]) = make_float4(z[2 * q].x, z[2 * q].y, z[2 * q + 1].x, z[2 * q + 1].y);
+    wave_lds_fence();
+    float2 y[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) y[r] = lds[lane + 64 * r];
+    wave_lds_fence();
+    wave_fft512<true>(y, lds, lane, tw);
+
+    const long first_emit = calls_before >= 1 ? 0 : 1;              // :201-204: the first call's block is dropped
+    if (j >= first_emit) {
+        short *o = out + (j - first_emit) * 512;
+        float *pc = precast ? precast + (j - first_emit) * 512 : nullptr;
+#pragma unroll
+        for (int dd = 0; dd < 8; dd++) {
+            const int i0 = 2 * lane + 128 * dd - 511;                // :193 rgsOutputBuffer[i] = y[i + 511] / 1024
+            const float s0 = y[dd].x * (1.0f / 1024.0f), s1 = y[dd].y * (1.0f / 1024.0f);
+            if (i0 >= 0 && i0 < 512) { o[i0] = (short)cast_i16_bits(s0); if (pc) pc[i0] = s0; }
+            if (i0 + 1 >= 0 && i0 + 1 < 512) { o[i0 + 1] = (short)cast_i16_bits(s1); if (pc) pc[i0 + 1] = s1; }
+        }
+    }
+    if (j == n_blocks - 1) {
+        reinterpret_cast<u32x4 *>(st_out->prev_l)[lane] = reinterpret_cast<const u32x4 *>(left + j * 512)[lane];
+        reinterpret_cast<u32x4 *>(st_out->prev_r)[lane] = reinterpret_cast<const u32x4 *>(right + j * 512)[lane];
+    }
+}
+
+int launch_mvdr(hipStream_t s, const short *left, const short *right, long n_blocks, long calls_before,
+                const MvdrState *st_in, MvdrState *st_out, const int *events, const DenoisePlan *plan,
+                const int *ver_base, const unsigned long long *snap_mask, double *delta, double *rver,
+                const double2 *steer, const float2 *table, short *out, float *precast)
+{
+    if (n_blocks <= 0) return 0;
+    const long g1 = n_blocks < 2048 ? n_blocks : 2048;
+    hipLaunchKernelGGL(mvdr_corr_kernel, dim3((unsigned)g1), dim3(64), 0, s, left, right, n_blocks, st_in, events, plan,
+                       table, delta);
+    hipLaunchKernelGGL(mvdr_prefix_kernel, dim3(1), dim3(64), 0, s, delta, plan, st_in, st_out, rver);
+    const long grid = (n_blocks + 7) / 8 * 8;
+    hipLaunchKernelGGL(mvdr_kernel, dim3((unsigned)grid), dim3(64), 0, s, left, right, n_blocks, calls_before, st_in,
+                       st_out, ver_base, snap_mask, rver, steer, table, out, precast);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+}  // namespace jdsp

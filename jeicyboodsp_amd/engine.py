@@ -59,6 +59,9 @@ class Engine:
     def fastconv(self, taps, n_fft):
         return FastConv(self, taps, n_fft)
 
+    def mvdr(self, d_time=0.0):
+        return Mvdr(self, d_time)
+
     def mfcc(self, **cfg):
         return Mfcc(self, **cfg)
 
@@ -359,3 +362,66 @@ class FastConv:
                                              (out if out.size else dummy).ctypes.data_as(C.c_void_p),
                                              pre.ctypes.data_as(C.c_void_p) if (want_precast and pre.size) else None, None))
         return (out, pre) if want_precast else out
+
+
+class Mvdr:
+    """Two-microphone MVDR beamformer (jdsp_mvdr): main()'s loop of BeamForming_MVDR_ver1.cpp:169-231
+    for batches of 512-sample blocks per channel."""
+
+    def __init__(self, engine, d_time=0.0):
+        self.eng = engine
+        h = C.c_void_p()
+        engine._ck(L.jdsp_mvdr_create(engine._h, float(d_time), C.byref(h)))
+        self._h = h
+        engine._children.append(self)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            L.jdsp_mvdr_destroy(self._h)
+            self._h = None
+            if self in self.eng._children:
+                self.eng._children.remove(self)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def reset(self):
+        self.eng._ck(L.jdsp_mvdr_reset(self._h))
+
+    def blocks_out(self, n_blocks):
+        return L.jdsp_mvdr_blocks_out(self._h, n_blocks)
+
+    def corr(self):
+        c = np.zeros(4, np.float64)
+        self.eng._ck(L.jdsp_mvdr_corr(self._h, c.ctypes.data_as(C.c_void_p)))
+        return c
+
+    def process(self, left, right, want_precast=False):
+        if _is_torch(left):
+            import torch
+            assert left.is_cuda and right.is_cuda and left.dtype == right.dtype == torch.int16
+            assert left.is_contiguous() and right.is_contiguous() and left.numel() == right.numel() and left.numel() % 512 == 0
+            nb = left.numel() // 512
+            n_out = self.blocks_out(nb)
+            out = torch.empty(max(n_out, 1) * 512, dtype=torch.int16, device=left.device)
+            pre = torch.empty(max(n_out, 1) * 512, dtype=torch.float32, device=left.device) if want_precast else None
+            self.eng._use_torch_stream()
+            self.eng._ck(L.jdsp_mvdr_process_dev(self._h, C.c_void_p(left.data_ptr()), C.c_void_p(right.data_ptr()), nb,
+                                                 C.c_void_p(out.data_ptr()),
+                                                 C.c_void_p(pre.data_ptr()) if want_precast else None, None))
+            out = out[:n_out * 512]
+            return (out, pre[:n_out * 512]) if want_precast else out
+        left = np.ascontiguousarray(left, np.int16)
+        right = np.ascontiguousarray(right, np.int16)
+        assert left.size == right.size and left.size % 512 == 0
+        nb = left.size // 512
+        n_out = self.blocks_out(nb)
+        out = np.zeros(max(n_out, 1) * 512, np.int16)
+        pre = np.zeros(max(n_out, 1) * 512, np.float32) if want_precast else None
+        self.eng._ck(L.jdsp_mvdr_process(self._h, left.ctypes.data_as(C.c_void_p), right.ctypes.data_as(C.c_void_p), nb,
+                                         out.ctypes.data_as(C.c_void_p),
+                                         pre.ctypes.data_as(C.c_void_p) if want_precast else None, None))
+        return (out[:n_out * 512], pre[:n_out * 512]) if want_precast else out[:n_out * 512]

@@ -10,6 +10,7 @@
  */
 #include "jdsp_oracle.h"
 
+#include <complex.h>
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -518,4 +519,105 @@ void orc_pitch_stream(const short *pcm, long n_blocks, int *arg, double *rmax, d
     }
     free(x);
     free(X);
+}
+
+/* ------------------------------------------------------------------------- */
+/* BeamForming_MVDR_ver1.cpp */
+#define MV_N 1024
+#define MV_BLOCK 512
+#define MV_KEEP 511
+
+/* :207-242: frame = [zeros(511) (keep buffer never updated, :240 unreachable), block, 0];
+ * only the energy decides (:233); the zero-crossing count is computed and ignored. */
+static int mvdr_vad(const short *block)
+{
+    double e = 0.0;
+    for (int i = 0; i < MV_BLOCK; i++) {
+        int p = MV_KEEP + i;
+        short s = (short)(block[i] * (0.54 - 0.46 * cos(2 * PI_APPS * p / (MV_N - 1))));   /* :217 */
+        e += pow(s, 2.0);                                                                   /* :221 */
+    }
+    e /= MV_N;                                                                              /* :229 */
+    return e > 700.0;                                                                       /* :233 */
+}
+
+long orc_mvdr_stream(const short *left, const short *right, long n_blocks, double d_time,
+                     short *out, double *pre_cast, double *corr4, double *corr_trace)
+{
+    orc_cplx *fl = (orc_cplx *)calloc(MV_N, sizeof(orc_cplx)), *FL = (orc_cplx *)calloc(MV_N, sizeof(orc_cplx));
+    orc_cplx *fr = (orc_cplx *)calloc(MV_N, sizeof(orc_cplx)), *FR = (orc_cplx *)calloc(MV_N, sizeof(orc_cplx));
+    orc_cplx *mg = (orc_cplx *)calloc(MV_N, sizeof(orc_cplx)), *MG = (orc_cplx *)calloc(MV_N, sizeof(orc_cplx));
+    double keep_l[MV_KEEP] = {0}, keep_r[MV_KEEP] = {0};               /* :259-261 */
+    short temp_l[2 * MV_BLOCK] = {0}, temp_r[2 * MV_BLOCK] = {0};      /* :111 */
+    double R[2][2] = {{0, 0}, {0, 0}};                                  /* :113 */
+    int iter = 0, count = 0;
+    long n_out = 0;
+    for (long b = 0; b < n_blocks; b++) {
+        const short *L = left + (size_t)b * MV_BLOCK, *Rr = right + (size_t)b * MV_BLOCK;
+        if (!mvdr_vad(L)) {                                            /* :191-211 */
+            iter++;
+            if (iter > 1) {
+                memcpy(temp_l + MV_BLOCK, L, sizeof(short) * MV_BLOCK);
+                memcpy(temp_r + MV_BLOCK, Rr, sizeof(short) * MV_BLOCK);
+                /* EstimateSpatialCorrMtx :244-270 */
+                for (int i = 0; i < MV_N; i++) { fl[i].re = temp_l[i]; fl[i].im = 0; fr[i].re = temp_r[i]; fr[i].im = 0; }
+                orc_dft_c2c(fl, FL, MV_N, -1);
+                orc_dft_c2c(fr, FR, MV_N, -1);
+                for (int i = 0; i < MV_N; i++) {
+                    R[0][0] += (pow(FL[i].re, 2.0) + pow(FL[i].im, 2.0)) / MV_N;
+                    R[0][1] += (-FL[i].re * FR[i].im + FL[i].im * FR[i].re) / MV_N;
+                    R[1][0] += (-FR[i].re * FL[i].im + FR[i].im * FL[i].re) / MV_N;
+                    R[1][1] += (pow(FR[i].re, 2.0) + pow(FR[i].im, 2.0)) / MV_N;
+                }
+            }
+            memcpy(temp_l, L, sizeof(short) * MV_BLOCK);
+            memcpy(temp_r, Rr, sizeof(short) * MV_BLOCK);
+        } else {
+            iter = 0;
+        }
+        if (corr_trace) { corr_trace[4 * b] = R[0][0]; corr_trace[4 * b + 1] = R[0][1]; corr_trace[4 * b + 2] = R[1][0]; corr_trace[4 * b + 3] = R[1][1]; }
+        /* ProcessMVDR :124-205 */
+        count++;
+        memset(fl, 0, sizeof(orc_cplx) * MV_N);
+        memset(fr, 0, sizeof(orc_cplx) * MV_N);
+        for (int i = 0; i < MV_KEEP; i++) { fl[i].re = keep_l[i]; fr[i].re = keep_r[i]; }               /* :136-137 */
+        for (int i = 0; i < MV_BLOCK; i++) { fl[i + MV_KEEP].re = L[i]; fr[i + MV_KEEP].re = Rr[i]; }   /* :138-141 */
+        orc_dft_c2c(fl, FL, MV_N, -1);
+        orc_dft_c2c(fr, FR, MV_N, -1);
+        {
+            /* mxAutoCorr.inverse() for a 2x2: adjugate times 1/det (complex scalars, zero imaginary parts) */
+            double complex a = R[0][0], bb = R[0][1], c = R[1][0], d = R[1][1];
+            double complex invdet = 1.0 / (a * d - bb * c);
+            double complex i00 = d * invdet, i01 = -bb * invdet, i10 = -c * invdet, i11 = a * invdet;
+            for (int i = 0; i < MV_N; i++) {
+                double ang = 2 * PI_APPS * i * (16000.0 / MV_N) * d_time;                /* :164-165 */
+                double complex s0 = 1.0, s1 = cos(ang) + I * sin(ang);
+                double complex w0 = i00 * s0 + i01 * s1, w1 = i10 * s0 + i11 * s1;       /* :170 */
+                double complex den = conj(s0) * w0 + conj(s1) * w1;                      /* :171 */
+                w0 /= den;
+                w1 /= den;
+                double lw0 = creal(w0), lw1 = -cimag(w0), rw0 = creal(w1), rw1 = -cimag(w1);   /* :175-178 */
+                /* :180-183 -- the imaginary part uses the ALREADY OVERWRITTEN real part */
+                FL[i].re = FL[i].re * lw0 - FL[i].im * lw1;
+                FL[i].im = FL[i].re * lw1 + FL[i].im * lw0;
+                FR[i].re = FR[i].re * rw0 - FR[i].im * rw1;
+                FR[i].im = FR[i].re * rw1 + FR[i].im * rw0;
+                mg[i].re = FL[i].re + FR[i].re;                                          /* :184-185 */
+                mg[i].im = FL[i].im + FR[i].im;
+            }
+        }
+        orc_dft_c2c(mg, MG, MV_N, +1);                                                   /* :189-190 */
+        if (count > 1) {                                                                 /* :201-204 */
+            for (int i = 0; i < MV_BLOCK; i++) {
+                double v = MG[i + MV_KEEP].re * 1. / MV_N;                               /* :193 */
+                out[(size_t)n_out * MV_BLOCK + i] = cast_i16(v);
+                if (pre_cast) pre_cast[(size_t)n_out * MV_BLOCK + i] = v;
+            }
+            n_out++;
+        }
+        for (int i = 0; i < MV_KEEP; i++) { keep_l[i] = fl[MV_KEEP + i].re; keep_r[i] = fr[MV_KEEP + i].re; }   /* :195-196 */
+    }
+    if (corr4) { corr4[0] = R[0][0]; corr4[1] = R[0][1]; corr4[2] = R[1][0]; corr4[3] = R[1][1]; }
+    free(fl); free(FL); free(fr); free(FR); free(mg); free(MG);
+    return n_out;
 }

@@ -111,6 +111,16 @@ long orc_mfcc_stream(const orc_mfcc_cfg *c, const short *pcm, long n_blocks, dou
  * arg[b], rmax[b] per block; autocorr (may be NULL) gets r[0..511] per block. */
 void orc_pitch_stream(const short *pcm, long n_blocks, int *arg, double *rmax, double *autocorr);
 
+/* BeamForming_MVDR_ver1.cpp: the whole main() loop (:169-231) for two
+ * channels of 512-sample blocks: energy VAD on the left channel (:207-242), spatial correlation
+ * accumulated over non-voice runs (:244-270), ProcessMVDR (:124-205) with steering delay
+ * d_time (the reference: 0, :60,:121).  Returns blocks written (n_blocks-1).  corr4 (may be NULL)
+ * receives the final rgdSpatialCorr in row-major order; corr_trace (may be NULL) receives the
+ * 2x2 matrix in effect for every block (4 doubles per block).  Until the matrix is
+ * invertible the reference's output is NaN; (short)NaN is 0 here as everywhere. */
+long orc_mvdr_stream(const short *left, const short *right, long n_blocks, double d_time,
+                     short *out, double *pre_cast, double *corr4, double *corr_trace);
+
 #ifdef __cplusplus
 }
 #endif

@@ -64,6 +64,9 @@ class Oracle:
                                           _c_short_p, _c_double_p]
         L.orc_fastconv_stream.restype = C.c_long
         L.orc_pitch_stream.argtypes = [_c_short_p, C.c_long, _c_int_p, _c_double_p, _c_double_p]
+        L.orc_mvdr_stream.argtypes = [_c_short_p, _c_short_p, C.c_long, C.c_double, _c_short_p, _c_double_p,
+                                      _c_double_p, _c_double_p]
+        L.orc_mvdr_stream.restype = C.c_long
         L.orc_mfcc_native_cfg.argtypes = [C.POINTER(MfccCfg)]
         L.orc_mel_init.argtypes = [C.POINTER(MfccCfg), _c_double_p, _c_int_p, _c_double_p]
         L.orc_mfcc_frame.argtypes = [C.POINTER(MfccCfg), _c_int_p, _c_double_p, _c_short_p, _c_double_p]
@@ -187,6 +190,18 @@ class Oracle:
         ac = np.zeros((nb, 512), np.float64)
         self.lib.orc_pitch_stream(_p(pcm, _c_short_p), nb, _p(arg, _c_int_p), _p(rmax, _c_double_p), _p(ac, _c_double_p))
         return arg, rmax, ac
+
+    def mvdr_stream(self, left, right, d_time=0.0):
+        left = np.ascontiguousarray(left, np.int16)
+        right = np.ascontiguousarray(right, np.int16)
+        nb = left.size // 512
+        out = np.zeros(max(nb, 1) * 512, np.int16)
+        pre = np.zeros(max(nb, 1) * 512, np.float64)
+        corr = np.zeros(4, np.float64)
+        trace = np.zeros((max(nb, 1), 4), np.float64)
+        n = self.lib.orc_mvdr_stream(_p(left, _c_short_p), _p(right, _c_short_p), nb, d_time, _p(out, _c_short_p),
+                                     _p(pre, _c_double_p), _p(corr, _c_double_p), _p(trace, _c_double_p))
+        return out[:n * 512].copy(), pre[:n * 512].copy(), corr, trace[:nb]
 
     def mfcc_native_cfg(self):
         c = MfccCfg()

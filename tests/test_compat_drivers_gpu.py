@@ -139,3 +139,31 @@ def test_driver_mfcc_list_file_carries_state_between_files(tmp_path, oracle):
     assert fa.shape == wa.shape == (11, 12) and fb.shape == wb.shape == (8, 12)
     for got, want in ((fa, wa), (fb, wb)):
         assert (np.abs(got - want) / np.abs(want).max(axis=1, keepdims=True)).max() < 1e-5
+
+
+def test_driver_mvdr_and_pitch1(tmp_path, oracle):
+    rng = np.random.default_rng(7)
+    n = 40 * 512
+    src = rng.normal(0, 3000, n)
+    L = src + rng.normal(0, 300, n)
+    R = 0.6 * src + rng.normal(0, 400, n)
+    L[:10 * 512] = rng.normal(0, 45, 10 * 512)
+    R[:10 * 512] = rng.normal(0, 60, 10 * 512)
+    cv = lambda x: np.clip(np.rint(x), -32768, 32767).astype(np.int16)
+    L, R = cv(L), cv(R)
+    for name, x in (("l.wav", L), ("r.wav", R)):
+        with open(tmp_path / name, "wb") as f:
+            f.write(bytes(44))
+            f.write(x.tobytes())
+    run("jdsp_mvdr", tmp_path / "l.wav", tmp_path / "r.wav", tmp_path / "o.raw")
+    got = np.fromfile(tmp_path / "o.raw", np.int16)
+    want, _, _, _ = oracle.mvdr_stream(L, R, 0.0)
+    assert got.shape == want.shape and np.abs(got.astype(np.int32) - want.astype(np.int32)).max() <= 1
+    res = subprocess.run([os.path.join(COMPAT, "jdsp_pitch1"), str(tmp_path / "l.wav")], check=True,
+                         capture_output=True, text=True, timeout=120)
+    lags = [int(l.split()[2]) for l in res.stdout.splitlines() if l.startswith("Estimation arg")]
+    o_arg, o_max, o_ac = oracle.pitch_stream(L)
+    lags = np.array(lags)
+    assert lags.shape == o_arg.shape
+    at_ours = o_ac[np.arange(len(lags)), lags]
+    assert np.all((lags == o_arg) | (o_max - at_ours <= 1e-5 * (o_ac[:, 0] + 1)))
