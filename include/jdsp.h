@@ -134,6 +134,26 @@ int jdsp_denoise_noise(jdsp_denoise *h, double *noise_host);
 int jdsp_denoise_vad_trace(jdsp_denoise *h, long n, uint8_t *voice_host, int64_t *energy_sum_host,
                            int32_t *zcr_host);
 
+/* Sharded denoise: one rank's share of ONE global stream of n_total blocks (multi-GPU,
+ * SURVEY §8e).  The rank owns global blocks [b0, b1); pcm_ext_dev holds global blocks
+ * [ext0, b1) with ext0 = max(b0 - 2, 0) (two halo blocks rebuild the overlap tail).  Between
+ * the steps the caller all-gathers three small buffers across ranks (any transport; RCCL in
+ * jeicyboodsp_amd/sharding.py):
+ *   1. shard_vad      -> flags_own (b1-b0 bytes)          all-gather -> flags_all (n_total bytes)
+ *   2. shard_summary  -> summary (1025 floats: the affine map A <- a*A + b of this rank's
+ *                         noise frames, SS:182-187)        all-gather -> summaries_all (world*1025)
+ *   3. shard_rows     -> last (1025 floats: latch count and last latched estimate, SS:189-193)
+ *                                                          all-gather -> last_all (world*1025)
+ *   4. shard_finish   -> out: the emitted blocks among [max(b0,2), b1), shard_blocks_out() of them
+ * Concatenating the ranks' outputs gives the single-GPU stream (int16 within +-1 LSB). */
+int jdsp_denoise_shard_vad_dev(jdsp_denoise *h, const int16_t *pcm_ext_dev, long ext0, long b0, long b1, long n_total,
+                               uint8_t *flags_own_dev);
+int jdsp_denoise_shard_summary_dev(jdsp_denoise *h, const uint8_t *flags_all_dev, float *summary_dev);
+int jdsp_denoise_shard_rows_dev(jdsp_denoise *h, const float *summaries_all_dev, int world, int rank, float *last_dev);
+long jdsp_denoise_shard_blocks_out(const jdsp_denoise *h);
+int jdsp_denoise_shard_finish_dev(jdsp_denoise *h, const float *last_all_dev, int world, int rank, int16_t *out_dev,
+                                  float *precast_dev, long *n_out_blocks);
+
 /* The reference's two helper functions on their own, for callers that keep main()'s
  * structure (jeicyboodsp_amd/compat): */
 /* VoiceActivityDetection (SS:121-156) for n_blocks blocks of 512 host samples; outputs as

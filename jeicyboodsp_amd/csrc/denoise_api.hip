@@ -15,6 +15,7 @@ static void free_workspace(jdsp_denoise *h)
     h->dbg_zcr = nullptr;
     h->mag = h->rows = nullptr;
     h->cap_blocks = 0;
+    h->cap_mag = 0;
 }
 
 extern "C" {
@@ -34,6 +35,10 @@ int jdsp_denoise_create(jdsp_ctx *ctx, int mode, jdsp_denoise **out)
     hipError_t e = hipSuccess;
     for (int i = 0; i < 2 && e == hipSuccess; i++) e = hipMalloc((void **)&h->st[i], sizeof(jdsp::DenoiseState));
     if (e == hipSuccess) e = hipMalloc((void **)&h->plan, sizeof(jdsp::DenoisePlan));
+    if (e == hipSuccess) e = hipMalloc((void **)&h->sh_range, 4 * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc((void **)&h->sh_a_in, 1024 * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void **)&h->sh_zero_run, sizeof(int));
+    if (e == hipSuccess) e = hipMemset(h->sh_zero_run, 0, sizeof(int));
     if (e == hipSuccess && jdsp::ensure_vad_window(ctx)) e = hipErrorUnknown;
     h->w_hi = ctx->vad_w_hi;
     if (e != hipSuccess) {
@@ -58,6 +63,9 @@ int jdsp_denoise_destroy(jdsp_denoise *h)
     for (int i = 0; i < 2; i++)
         if (h->st[i]) (void)hipFree(h->st[i]);
     if (h->plan) (void)hipFree(h->plan);
+    if (h->sh_range) (void)hipFree(h->sh_range);
+    if (h->sh_a_in) (void)hipFree(h->sh_a_in);
+    if (h->sh_zero_run) (void)hipFree(h->sh_zero_run);
     delete h;
     return JDSP_OK;
 }
@@ -90,11 +98,21 @@ long jdsp_denoise_blocks_out(const jdsp_denoise *h, long n_blocks)
     return n_blocks > first_emit ? n_blocks - first_emit : 0;
 }
 
+static int reserve2(jdsp_denoise *h, long max_blocks, long mag_blocks);
+
 int jdsp_denoise_reserve(jdsp_denoise *h, long max_blocks)
 {
     if (!h || max_blocks < 0) return JDSP_EINVAL;
+    return reserve2(h, max_blocks, max_blocks);
+}
+
+// max_blocks: blocks the run-length plan covers; mag_blocks: blocks whose magnitudes this GPU may hold
+static int reserve2(jdsp_denoise *h, long max_blocks, long mag_blocks)
+{
     jdsp_ctx *ctx = h->ctx;
-    if (max_blocks <= h->cap_blocks) return JDSP_OK;
+    if (max_blocks <= h->cap_blocks && mag_blocks <= h->cap_mag) return JDSP_OK;
+    if (max_blocks < h->cap_blocks) max_blocks = h->cap_blocks;
+    if (mag_blocks < h->cap_mag) mag_blocks = h->cap_mag;
     JDSP_HIP(ctx, hipSetDevice(ctx->device));
     JDSP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     free_workspace(h);
@@ -107,13 +125,15 @@ int jdsp_denoise_reserve(jdsp_denoise *h, long max_blocks)
     if (e == hipSuccess) e = hipMalloc((void **)&h->dbg_energy, n * sizeof(long long));
     if (e == hipSuccess) e = hipMalloc((void **)&h->dbg_zcr, n * sizeof(int));
     // worst case: every block feeds the noise average; an estimate can latch at most every 10th block
-    if (e == hipSuccess) e = hipMalloc((void **)&h->mag, n * 1024 * sizeof(float));
-    if (e == hipSuccess) e = hipMalloc((void **)&h->rows, (n / 10 + 2) * 1024 * sizeof(float));
+    const size_t nm = (size_t)(mag_blocks > 0 ? mag_blocks : 1);
+    if (e == hipSuccess) e = hipMalloc((void **)&h->mag, nm * 1024 * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void **)&h->rows, (nm / 10 + 2) * 1024 * sizeof(float));
     if (e != hipSuccess) {
         free_workspace(h);
         return fail(ctx, e == hipErrorOutOfMemory ? JDSP_ENOMEM : JDSP_EHIP, "jdsp_denoise_reserve", e);
     }
     h->cap_blocks = max_blocks;
+    h->cap_mag = mag_blocks;
     return JDSP_OK;
 }
 
@@ -265,6 +285,94 @@ int jdsp_vad_blocks(jdsp_ctx *ctx, const int16_t *pcm_host, long n_blocks, uint8
     if (d_e) (void)hipFree(d_e);
     if (d_z) (void)hipFree(d_z);
     return rc;
+}
+
+/* ---- multi-GPU: one rank's share of a stream (include/jdsp.h "sharded denoise") ------------- */
+int jdsp_denoise_shard_vad_dev(jdsp_denoise *h, const int16_t *pcm_ext_dev, long ext0, long b0, long b1, long n_total,
+                               uint8_t *flags_own_dev)
+{
+    if (!h) return JDSP_EINVAL;
+    jdsp_ctx *ctx = h->ctx;
+    if (!(0 <= ext0 && ext0 <= b0 && b0 <= b1 && b1 <= n_total) || (b0 >= 2 ? ext0 != b0 - 2 : ext0 != 0))
+        return fail(ctx, JDSP_EINVAL, "jdsp_denoise_shard_vad: need ext0 = max(b0-2, 0) <= b0 <= b1 <= n_total");
+    if (b1 > b0 && (!pcm_ext_dev || !flags_own_dev)) return fail(ctx, JDSP_EINVAL, "jdsp_denoise_shard_vad: NULL buffer");
+    if ((uintptr_t)pcm_ext_dev & 15u) return fail(ctx, JDSP_EINVAL, "jdsp_denoise_shard_vad: pcm must be 16-byte aligned");
+    JDSP_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = reserve2(h, n_total, b1 - b0 + 1);
+    if (rc) return rc;
+    rc = jdsp_denoise_reset(h);                       // a sharded run is one fresh global stream
+    if (rc) return rc;
+    h->sh_ext0 = ext0; h->sh_b0 = b0; h->sh_b1 = b1; h->sh_total = n_total; h->sh_pcm = pcm_ext_dev;
+    if (jdsp::launch_vad(ctx->stream, pcm_ext_dev + (b0 - ext0) * 512, b1 - b0, h->w_hi, 1, flags_own_dev, nullptr,
+                         nullptr))
+        return fail(ctx, JDSP_EHIP, "vad launch", hipGetLastError());
+    return JDSP_OK;
+}
+
+int jdsp_denoise_shard_summary_dev(jdsp_denoise *h, const uint8_t *flags_all_dev, float *summary_dev)
+{
+    if (!h) return JDSP_EINVAL;
+    jdsp_ctx *ctx = h->ctx;
+    if (!h->sh_pcm && h->sh_b1 > h->sh_b0) return fail(ctx, JDSP_EINVAL, "jdsp_denoise_shard_summary: call shard_vad first");
+    if (!flags_all_dev || !summary_dev) return fail(ctx, JDSP_EINVAL, "jdsp_denoise_shard_summary: NULL buffer");
+    JDSP_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    if (jdsp::launch_run_plan(s, flags_all_dev, h->sh_total, h->sh_zero_run, nullptr, 10, h->ver_base, h->snap_mask,
+                              h->events, h->ev_n, h->plan) ||
+        jdsp::launch_shard_summary(s, h->sh_pcm, h->sh_b1 - h->sh_ext0, h->sh_ext0, h->sh_b0, h->sh_b1, h->events, h->ev_n,
+                                   h->plan, h->ver_base, h->snap_mask, ctx->stft1024_table, h->sh_range, h->mag,
+                                   summary_dev))
+        return fail(ctx, JDSP_EHIP, "shard summary launch", hipGetLastError());
+    return JDSP_OK;
+}
+
+int jdsp_denoise_shard_rows_dev(jdsp_denoise *h, const float *summaries_all_dev, int world, int rank, float *last_dev)
+{
+    if (!h) return JDSP_EINVAL;
+    jdsp_ctx *ctx = h->ctx;
+    if (!summaries_all_dev || !last_dev || world < 1 || rank < 0 || rank >= world)
+        return fail(ctx, JDSP_EINVAL, "jdsp_denoise_shard_rows: bad argument");
+    JDSP_HIP(ctx, hipSetDevice(ctx->device));
+    if (jdsp::launch_shard_rows(ctx->stream, summaries_all_dev, rank, h->ev_n, h->sh_range, h->mag, h->sh_a_in, h->rows,
+                                last_dev))
+        return fail(ctx, JDSP_EHIP, "shard rows launch", hipGetLastError());
+    return JDSP_OK;
+}
+
+long jdsp_denoise_shard_blocks_out(const jdsp_denoise *h)
+{
+    if (!h) return 0;
+    const long lo = h->sh_b0 > 2 ? h->sh_b0 : 2;                      // SS:260-263: global blocks 0 and 1 emit nothing
+    return h->sh_b1 > lo ? h->sh_b1 - lo : 0;
+}
+
+int jdsp_denoise_shard_finish_dev(jdsp_denoise *h, const float *last_all_dev, int world, int rank, int16_t *out_dev,
+                                  float *precast_dev, long *n_out_blocks)
+{
+    if (!h) return JDSP_EINVAL;
+    jdsp_ctx *ctx = h->ctx;
+    const long n_out = jdsp_denoise_shard_blocks_out(h);
+    if (n_out_blocks) *n_out_blocks = n_out;
+    if (!last_all_dev || world < 1 || rank < 0 || rank >= world || (n_out > 0 && !out_dev))
+        return fail(ctx, JDSP_EINVAL, "jdsp_denoise_shard_finish: bad argument");
+    if ((uintptr_t)out_dev & 15u) return fail(ctx, JDSP_EINVAL, "jdsp_denoise_shard_finish: out must be 16-byte aligned");
+    JDSP_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    if (jdsp::launch_shard_row0(s, last_all_dev, rank, h->rows)) return fail(ctx, JDSP_EHIP, "row0 launch", hipGetLastError());
+    if (n_out > 0) {
+        jdsp::DenoiseShard sh;
+        sh.ver_block_off = h->sh_ext0;
+        sh.ver_row_off = h->sh_range + 2;
+        const long lo = h->sh_b0 > 2 ? h->sh_b0 : 2;
+        sh.emit_from = lo - h->sh_ext0;
+        sh.emit_to = h->sh_b1 - h->sh_ext0;
+        // fresh state: the two halo blocks in front of the shard rebuild the overlap tail
+        if (jdsp::launch_denoise(s, h->mode, h->opt_k, h->sh_pcm, h->sh_b1 - h->sh_ext0, h->sh_ext0, h->st[h->cur],
+                                 h->st[h->cur ^ 1], h->ver_base, h->snap_mask, h->rows, ctx->stft1024_table, out_dev,
+                                 precast_dev, &sh))
+            return fail(ctx, JDSP_EHIP, "denoise launch", hipGetLastError());
+    }
+    return JDSP_OK;
 }
 
 int jdsp_denoise_noise(jdsp_denoise *h, double *noise_host)

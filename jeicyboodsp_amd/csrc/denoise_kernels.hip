@@ -361,12 +361,25 @@ __device__ __forceinline__ void denoise_frame(const unsigned int *raw, const Fra
 #define JDSP_DENOISE_MINWAVES 3
 #endif
 
+// Which noise row block j (local index) uses.  Single-GPU: the plan's version.  Sharded
+// (DenoiseShard): the plan is indexed by GLOBAL block number and the local row table starts at
+// the estimate in effect at the block before the shard (row 0).
+__device__ __forceinline__ const float *noise_row(const float *__restrict__ rows, const int *__restrict__ ver_base,
+                                                  const unsigned long long *__restrict__ snap_mask, long j,
+                                                  const DenoiseShard &sh)
+{
+    int v = version_of(ver_base, snap_mask, j + sh.ver_block_off);
+    if (sh.ver_row_off) v -= *sh.ver_row_off;
+    if (v < 0) v = 0;
+    return rows + (size_t)v * 1024;
+}
+
 template <int MODE, int K>
 __global__ __launch_bounds__(64, JDSP_DENOISE_MINWAVES) void denoise_kernel(
     const short *__restrict__ pcm, long n_blocks, long calls_before, const DenoiseState *__restrict__ st_in,
     DenoiseState *st_out, const int *__restrict__ ver_base, const unsigned long long *__restrict__ snap_mask,
     const float *__restrict__ noise_rows, const float2 *__restrict__ table, short *__restrict__ out,
-    float *__restrict__ precast)
+    float *__restrict__ precast, DenoiseShard sh)
 {
     __shared__ __attribute__((aligned(16))) float2 lds[kWaveLdsComplex];
     __shared__ __attribute__((aligned(16))) unsigned int stage[256];
@@ -381,7 +394,7 @@ __global__ __launch_bounds__(64, JDSP_DENOISE_MINWAVES) void denoise_kernel(
     FrameTables t;
     load_frame_tables(t, table, lane);
 
-    const long first_emit = calls_before >= 2 ? 0 : 2 - calls_before;   // SS:260-263: calls 1 and 2 emit nothing
+    const long first_emit = sh.emit_from;                     // SS:260-263: calls 1 and 2 emit nothing
     unsigned int raw[8];
     float2 tail[4], y[8];
     relayout_half(stage, lane, half[0], raw);
@@ -395,7 +408,7 @@ __global__ __launch_bounds__(64, JDSP_DENOISE_MINWAVES) void denoise_kernel(
 #pragma unroll
         for (int d = 0; d < 4; d++) tail[d] = make_float2(0.f, 0.f);
     } else {
-        denoise_frame<MODE>(raw, t, lds, lane, noise_rows + (size_t)version_of(ver_base, snap_mask, j0 - 1) * 1024, y);   // halo frame
+        denoise_frame<MODE>(raw, t, lds, lane, noise_row(noise_rows, ver_base, snap_mask, j0 - 1, sh), y);   // halo frame
 #pragma unroll
         for (int d = 0; d < 4; d++) tail[d] = y[d + 4];
     }
@@ -411,7 +424,7 @@ __global__ __launch_bounds__(64, JDSP_DENOISE_MINWAVES) void denoise_kernel(
 #pragma unroll
             for (int d = 0; d < 8; d++) y[d] = make_float2(0.f, 0.f);
         } else {
-            denoise_frame<MODE>(raw, t, lds, lane, noise_rows + (size_t)version_of(ver_base, snap_mask, j) * 1024, y);
+            denoise_frame<MODE>(raw, t, lds, lane, noise_row(noise_rows, ver_base, snap_mask, j, sh), y);
         }
         float2 o[4];
 #pragma unroll
@@ -419,7 +432,7 @@ __global__ __launch_bounds__(64, JDSP_DENOISE_MINWAVES) void denoise_kernel(
             o[d] = make_float2(tail[d].x + y[d].x, tail[d].y + y[d].y);      // SS:248 overlap-add
             tail[d] = y[d + 4];                                               // SS:255-256
         }
-        if (j >= first_emit) {
+        if (j >= first_emit && j < sh.emit_to) {
             const long oi = j - first_emit;
 #pragma unroll
             for (int d = 0; d < 4; d++) stage[lane + 64 * d] = cast_i16_bits(o[d].x) | (cast_i16_bits(o[d].y) << 16);
@@ -438,6 +451,142 @@ __global__ __launch_bounds__(64, JDSP_DENOISE_MINWAVES) void denoise_kernel(
             for (int d = 0; d < 4; d++) *reinterpret_cast<float2 *>(&st_out->tail[2 * lane + 128 * d]) = tail[d];
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------
+// Multi-GPU sharding of the noise estimate.  Rank r owns blocks [b0, b1) of the
+// global stream.  The run-length plan is replicated (every rank runs plan_kernel over the
+// all-gathered voice flags); the running average A (SS:182-187) is an affine recurrence
+// A <- a*A + b over the events, so each rank reduces its own events to one (alpha, beta[1024])
+// pair, the pairs are all-gathered, and every rank folds the pairs of the ranks before it to get
+// the A it starts from.  Latched estimates (SS:189-193) are then absolute, and only the last
+// one per rank has to travel.
+__global__ void event_range_kernel(const int *__restrict__ events, const DenoisePlan *__restrict__ plan,
+                                   const int *__restrict__ ver_base, const unsigned long long *__restrict__ snap_mask,
+                                   long b0, long b1, int *__restrict__ range)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int n = plan->n_events;
+    int lo = 0, hi = n;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (events[mid] < b0) lo = mid + 1; else hi = mid; }
+    range[0] = lo;
+    hi = n;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (events[mid] < b1) lo = mid + 1; else hi = mid; }
+    range[1] = lo;
+    range[2] = b0 > 0 ? version_of(ver_base, snap_mask, b0 - 1) : 0;     // latches before the shard = row offset
+}
+
+__global__ __launch_bounds__(64) void noise_mag_range_kernel(const short *__restrict__ pcm_ext, long n_ext, long ext0,
+                                                             const int *__restrict__ events,
+                                                             const int *__restrict__ range,
+                                                             const float2 *__restrict__ table, float *__restrict__ mag)
+{
+    __shared__ __attribute__((aligned(16))) float2 lds[kWaveLdsComplex];
+    __shared__ __attribute__((aligned(16))) unsigned int stage[256];
+    const int lane = threadIdx.x;
+    const int e0 = range[0], e1 = range[1];
+    if (e0 + (int)blockIdx.x >= e1) return;
+    FrameTables t;
+    load_frame_tables(t, table, lane);
+    for (int e = e0 + blockIdx.x; e < e1; e += gridDim.x) {
+        const long j = events[e] - ext0;                                  // local block index, >= 1
+        const u32x4 h0 = load_block(pcm_ext, n_ext, nullptr, j - 1 >= 0 ? j - 1 : -2, lane);
+        const u32x4 h1 = load_block(pcm_ext, n_ext, nullptr, j, lane);
+        unsigned int raw[8];
+        relayout_half(stage, lane, h0, raw);
+        relayout_half(stage, lane, h1, raw + 4);
+        forward_to_lds(raw, t, lds, lane);
+        float *dst = mag + (size_t)(e - e0) * 1024;
+        mag_store_j<0>(lds, lane, t.wsp, dst);
+        mag_store_j<1>(lds, lane, t.wsp, dst);
+        mag_store_j<2>(lds, lane, t.wsp, dst);
+        mag_store_j<3>(lds, lane, t.wsp, dst);
+        wave_lds_fence();
+    }
+}
+
+// One pass over this rank's events from the average `a_in` (NULL: zero).  summary (may be NULL):
+// [0] = alpha = 2^-(number of halvings), [1..1024] = the average after the last event.
+// rows (may be NULL): row k >= 1 = the k-th estimate latched inside the shard.
+// last (may be NULL): [0] = number of latches, [1..1024] = the last one.
+__global__ __launch_bounds__(256) void noise_scan_range_kernel(const float *__restrict__ mag, const int *__restrict__ ev_n,
+                                                               const int *__restrict__ range,
+                                                               const float *__restrict__ a_in, float *__restrict__ summary,
+                                                               float *__restrict__ rows, float *__restrict__ last)
+{
+    const int bin = blockIdx.x * blockDim.x + threadIdx.x;
+    const int e0 = range[0], e1 = range[1];
+    float avg = a_in ? a_in[bin] : 0.f;
+    float alpha = 1.f, latched = 0.f;
+    int row = 0;
+    for (int e = e0; e < e1; e++) {
+        const int n = ev_n[e];
+        avg += mag[(size_t)(e - e0) * 1024 + bin];
+        if (n >= 3) { avg *= 0.5f; alpha *= 0.5f; }
+        if (n == 10) {
+            row++;
+            latched = avg;
+            if (rows) rows[(size_t)row * 1024 + bin] = avg;
+        }
+    }
+    if (summary) {
+        summary[1 + bin] = avg;
+        if (bin == 0) summary[0] = alpha;
+    }
+    if (last) {
+        last[1 + bin] = latched;
+        if (bin == 0) last[0] = (float)row;
+    }
+}
+
+// A entering rank `rank` = the pairs of the ranks before it applied in order.
+__global__ __launch_bounds__(256) void fold_summaries_kernel(const float *__restrict__ all, int rank, float *__restrict__ a_in)
+{
+    const int bin = blockIdx.x * blockDim.x + threadIdx.x;
+    float a = 0.f;
+    for (int q = 0; q < rank; q++) a = all[(size_t)q * 1025] * a + all[(size_t)q * 1025 + 1 + bin];
+    a_in[bin] = a;
+}
+
+// rows[0] = the estimate in effect at the block before the shard: the last latch of the nearest
+// earlier rank that has one (zeros if none: rgdEstimatedNS starts at 0, SS:70).
+__global__ __launch_bounds__(256) void select_row0_kernel(const float *__restrict__ last_all, int rank, float *__restrict__ rows)
+{
+    const int bin = blockIdx.x * blockDim.x + threadIdx.x;
+    float v = 0.f;
+    for (int q = rank - 1; q >= 0; q--)
+        if (last_all[(size_t)q * 1025] > 0.f) { v = last_all[(size_t)q * 1025 + 1 + bin]; break; }
+    rows[bin] = v;
+}
+
+int launch_shard_summary(hipStream_t s, const short *pcm_ext, long n_ext, long ext0, long b0, long b1,
+                         const int *events, const int *ev_n, const DenoisePlan *plan, const int *ver_base,
+                         const unsigned long long *snap_mask, const float2 *table, int *range, float *mag,
+                         float *summary)
+{
+    hipLaunchKernelGGL(event_range_kernel, dim3(1), dim3(64), 0, s, events, plan, ver_base, snap_mask, b0, b1, range);
+    const long own = b1 - b0;
+    const long grid = own < 4096 ? (own > 0 ? own : 1) : 4096;
+    hipLaunchKernelGGL(noise_mag_range_kernel, dim3((unsigned)grid), dim3(64), 0, s, pcm_ext, n_ext, ext0, events, range,
+                       table, mag);
+    hipLaunchKernelGGL(noise_scan_range_kernel, dim3(4), dim3(256), 0, s, mag, ev_n, range, (const float *)nullptr,
+                       summary, (float *)nullptr, (float *)nullptr);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+int launch_shard_rows(hipStream_t s, const float *summaries_all, int rank, const int *ev_n, const int *range,
+                      const float *mag, float *a_in, float *rows, float *last)
+{
+    hipLaunchKernelGGL(fold_summaries_kernel, dim3(4), dim3(256), 0, s, summaries_all, rank, a_in);
+    hipLaunchKernelGGL(noise_scan_range_kernel, dim3(4), dim3(256), 0, s, mag, ev_n, range, (const float *)a_in,
+                       (float *)nullptr, rows, last);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+int launch_shard_row0(hipStream_t s, const float *last_all, int rank, float *rows)
+{
+    hipLaunchKernelGGL(select_row0_kernel, dim3(4), dim3(256), 0, s, last_all, rank, rows);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -485,20 +634,28 @@ int launch_noise_estimate(hipStream_t s, const short *pcm, long n_blocks, const 
 template <int MODE, int K>
 static void launch_dn(hipStream_t s, const short *pcm, long n_blocks, long calls_before, const DenoiseState *st_in,
                       DenoiseState *st_out, const int *ver_base, const unsigned long long *snap_mask,
-                      const float *noise_rows, const float2 *table, short *out, float *precast)
+                      const float *noise_rows, const float2 *table, short *out, float *precast, const DenoiseShard &sh)
 {
     long grid = ((n_blocks + K - 1) / K + 7) / 8 * 8;
     hipLaunchKernelGGL((denoise_kernel<MODE, K>), dim3((unsigned)grid), dim3(64), 0, s, pcm, n_blocks, calls_before,
-                       st_in, st_out, ver_base, snap_mask, noise_rows, table, out, precast);
+                       st_in, st_out, ver_base, snap_mask, noise_rows, table, out, precast, sh);
 }
 
 int launch_denoise(hipStream_t s, int mode, int k_opt, const short *pcm, long n_blocks, long calls_before,
                    const DenoiseState *st_in, DenoiseState *st_out, const int *ver_base,
                    const unsigned long long *snap_mask, const float *noise_rows, const float2 *table, short *out,
-                   float *precast)
+                   float *precast, const DenoiseShard *shard)
 {
     if (n_blocks <= 0) return 0;
-#define JDSP_DN(M, KK) launch_dn<M, KK>(s, pcm, n_blocks, calls_before, st_in, st_out, ver_base, snap_mask, noise_rows, table, out, precast)
+    DenoiseShard sh;
+    if (shard) sh = *shard;
+    else {
+        sh.ver_block_off = 0;
+        sh.ver_row_off = nullptr;
+        sh.emit_from = calls_before >= 2 ? 0 : 2 - calls_before;
+        sh.emit_to = n_blocks;
+    }
+#define JDSP_DN(M, KK) launch_dn<M, KK>(s, pcm, n_blocks, calls_before, st_in, st_out, ver_base, snap_mask, noise_rows, table, out, precast, sh)
     if (mode == 0) {
         switch (k_opt) {
         case 1: JDSP_DN(0, 1); break;

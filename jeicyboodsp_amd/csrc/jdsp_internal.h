@@ -40,6 +40,13 @@ struct DenoiseState {
 };
 struct DenoisePlan { int n_events, n_snap, pad0, pad1; };
 
+// How denoise_kernel maps local block indices onto the (possibly global) plan and what it emits.
+struct DenoiseShard {
+    long ver_block_off;        // global index of local block 0 (0 when not sharded)
+    const int *ver_row_off;    // device int: latches before the shard, subtracted from the version (or NULL)
+    long emit_from, emit_to;   // local block range written to `out`
+};
+
 // BeamForming_MVDR_ver1.cpp's state between calls (device memory)
 struct MvdrState {
     int run_len;          // main(): iNumOfIteration             MVDR:59,99,108
@@ -97,7 +104,14 @@ int launch_noise_estimate(hipStream_t s, const short *pcm, long n_blocks, const 
 int launch_denoise(hipStream_t s, int mode, int k_opt, const short *pcm, long n_blocks, long calls_before,
                    const DenoiseState *st_in, DenoiseState *st_out, const int *ver_base,
                    const unsigned long long *snap_mask, const float *noise_rows, const float2 *table, short *out,
-                   float *precast);
+                   float *precast, const DenoiseShard *shard = nullptr);
+int launch_shard_summary(hipStream_t s, const short *pcm_ext, long n_ext, long ext0, long b0, long b1,
+                         const int *events, const int *ev_n, const DenoisePlan *plan, const int *ver_base,
+                         const unsigned long long *snap_mask, const float2 *table, int *range, float *mag,
+                         float *summary);
+int launch_shard_rows(hipStream_t s, const float *summaries_all, int rank, const int *ev_n, const int *range,
+                      const float *mag, float *a_in, float *rows, float *last);
+int launch_shard_row0(hipStream_t s, const float *last_all, int rank, float *rows);
 int ensure_stft1024_table(jdsp_ctx *ctx);
 int ensure_vad_window(jdsp_ctx *ctx);
 // fastconv_kernels.hip
@@ -139,7 +153,8 @@ struct jdsp_denoise {
     jdsp::DenoiseState *st[2] = {nullptr, nullptr};
     int cur = 0;                          // st[cur] is the state the next call reads
     double *w_hi = nullptr;               // second half of the FP64 Hamming window (VAD)
-    long cap_blocks = 0;                  // workspace capacity
+    long cap_blocks = 0;                  // workspace capacity (plan arrays)
+    long cap_mag = 0;                     // workspace capacity (magnitude rows)
     unsigned char *flags = nullptr;
     int *ev_n = nullptr, *ver_base = nullptr, *events = nullptr;
     unsigned long long *snap_mask = nullptr;
@@ -149,6 +164,12 @@ struct jdsp_denoise {
     float *mag = nullptr, *rows = nullptr;
     long last_blocks = 0;
     int opt_k = 0;
+    // sharded (multi-GPU) run in progress: jdsp_denoise_shard_*
+    long sh_ext0 = 0, sh_b0 = 0, sh_b1 = 0, sh_total = 0;
+    const int16_t *sh_pcm = nullptr;
+    int *sh_range = nullptr;              // device: {first event, one past last event, latches before the shard}
+    float *sh_a_in = nullptr;             // device: [1024]
+    int *sh_zero_run = nullptr;           // device: a zero (run length entering a fresh global stream)
 };
 
 struct jdsp_mfcc {

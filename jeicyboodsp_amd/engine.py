@@ -216,6 +216,41 @@ class Denoiser:
         assert got.value == n_out
         return (out[:n_out * 512], pre[:n_out * 512]) if want_precast else out[:n_out * 512]
 
+    # ---- one rank's share of a global stream (jdsp_denoise_shard_*; driver: sharding.denoise_sharded)
+    def shard_vad(self, pcm_ext, ext0, b0, b1, n_total):
+        import torch
+        flags = torch.empty(max(b1 - b0, 1), dtype=torch.uint8, device=pcm_ext.device)
+        self.eng._use_torch_stream()
+        self.eng._ck(L.jdsp_denoise_shard_vad_dev(self._h, C.c_void_p(pcm_ext.data_ptr()), ext0, b0, b1, n_total,
+                                                  C.c_void_p(flags.data_ptr())))
+        return flags[: b1 - b0]
+
+    def shard_summary(self, flags_all):
+        import torch
+        out = torch.empty(1025, dtype=torch.float32, device=flags_all.device)
+        self.eng._use_torch_stream()
+        self.eng._ck(L.jdsp_denoise_shard_summary_dev(self._h, C.c_void_p(flags_all.data_ptr()), C.c_void_p(out.data_ptr())))
+        return out
+
+    def shard_rows(self, summaries_all, world, rank):
+        import torch
+        out = torch.empty(1025, dtype=torch.float32, device=summaries_all.device)
+        self.eng._use_torch_stream()
+        self.eng._ck(L.jdsp_denoise_shard_rows_dev(self._h, C.c_void_p(summaries_all.data_ptr()), world, rank,
+                                                   C.c_void_p(out.data_ptr())))
+        return out
+
+    def shard_finish(self, last_all, world, rank, want_precast=False):
+        import torch
+        n_out = L.jdsp_denoise_shard_blocks_out(self._h)
+        out = torch.empty(max(n_out, 1) * 512, dtype=torch.int16, device=last_all.device)
+        pre = torch.empty(max(n_out, 1) * 512, dtype=torch.float32, device=last_all.device) if want_precast else None
+        self.eng._use_torch_stream()
+        self.eng._ck(L.jdsp_denoise_shard_finish_dev(self._h, C.c_void_p(last_all.data_ptr()), world, rank,
+                                                     C.c_void_p(out.data_ptr()),
+                                                     C.c_void_p(pre.data_ptr()) if want_precast else None, None))
+        return (out[: n_out * 512], pre[: n_out * 512]) if want_precast else out[: n_out * 512]
+
     def noise(self):
         n = np.zeros(1024, np.float64)
         self.eng._ck(L.jdsp_denoise_noise(self._h, n.ctypes.data_as(C.c_void_p)))

@@ -77,3 +77,27 @@ def all_gather_rows(local, counts, dist, group=None):
     if all(c == longest for c in counts):
         return out
     return torch.cat([out[r * longest: r * longest + counts[r]] for r in range(world)])
+
+
+def denoise_shard_range(n_blocks, rank, world):
+    """Blocks [b0, b1) a rank owns and the first block it must be given (two halo blocks)."""
+    b0, count = split_even(n_blocks, rank, world)
+    return max(b0 - 2, 0), b0, b0 + count
+
+
+def denoise_sharded(denoiser, pcm_ext, ext0, b0, b1, n_total, rank, world, gather):
+    """One rank's part of a spectral-subtraction / Wiener run over ONE global stream.
+
+    pcm_ext: torch int16 CUDA tensor with global blocks [ext0, b1).  gather(t, counts) must return
+    the concatenation over ranks of each rank's t (counts[r] rows of it): with torch.distributed,
+    ``lambda t, c: all_gather_rows(t, c, dist)``.  Three small exchanges (voice flags, one
+    (alpha, beta[1024]) pair per rank, one latched estimate per rank); the heavy kernels see
+    only the rank's own blocks.  Returns the rank's emitted int16 blocks."""
+    own = [split_even(n_total, r, world)[1] for r in range(world)]
+    flags_own = denoiser.shard_vad(pcm_ext, ext0, b0, b1, n_total)
+    flags_all = gather(flags_own.reshape(-1, 1), own).reshape(-1).contiguous()
+    summary = denoiser.shard_summary(flags_all)
+    summaries = gather(summary.reshape(1, -1), [1] * world).contiguous()
+    last = denoiser.shard_rows(summaries, world, rank)
+    lasts = gather(last.reshape(1, -1), [1] * world).contiguous()
+    return denoiser.shard_finish(lasts, world, rank)
