@@ -660,15 +660,15 @@ int launch_denoise(hipStream_t s, int mode, int k_opt, const short *pcm, long n_
         switch (k_opt) {
         case 1: JDSP_DN(0, 1); break;
         case 2: JDSP_DN(0, 2); break;
-        case 8: JDSP_DN(0, 8); break;
-        default: JDSP_DN(0, 4); break;
+        case 4: JDSP_DN(0, 4); break;
+        default: JDSP_DN(0, 8); break;
         }
     } else {
         switch (k_opt) {
         case 1: JDSP_DN(1, 1); break;
         case 2: JDSP_DN(1, 2); break;
-        case 8: JDSP_DN(1, 8); break;
-        default: JDSP_DN(1, 4); break;
+        case 4: JDSP_DN(1, 4); break;
+        default: JDSP_DN(1, 8); break;
         }
     }
 #undef JDSP_DN

@@ -76,10 +76,18 @@ __global__ __launch_bounds__(64) void fastconv1024_kernel(ConvStream s, long n_o
     load_wave_twiddles(tw, table, lane);
     float2 wsp[2] = {table[kStftSplit + 2 * lane], table[kStftSplit + 2 * lane + 1]};
     float2 v[8];
+    // common case: the whole 1024-sample segment lies inside this call's buffer and past the
+    // stream's silent head -> plain 16-bit loads, no per-sample tests (wave-uniform branch)
+    if (end - 1024 >= 0 && end <= s.n_samples && end - 1024 + s.global0 >= s.valid_from) {
+        const short *src = s.pcm + (end - 1024) + 2 * lane;
 #pragma unroll
-    for (int r = 0; r < 8; r++) {
-        const long p0 = end - 1024 + 2 * lane + 128 * r;
-        v[r] = make_float2(0.5f * conv_sample(s, p0), 0.5f * conv_sample(s, p0 + 1));   // 0.5: split convention
+        for (int r = 0; r < 8; r++) v[r] = make_float2(0.5f * (float)src[128 * r], 0.5f * (float)src[128 * r + 1]);
+    } else {
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const long p0 = end - 1024 + 2 * lane + 128 * r;
+            v[r] = make_float2(0.5f * conv_sample(s, p0), 0.5f * conv_sample(s, p0 + 1));   // 0.5: split convention
+        }
     }
     wave_fft512<false>(v, lds, lane, tw);
 #pragma unroll
@@ -101,16 +109,22 @@ __global__ __launch_bounds__(64) void fastconv1024_kernel(ConvStream s, long n_o
         wave_lds_fence();
         wave_fft512<true>(y, lds, lane, tw);
         wave_lds_fence();
-        // keep y[n_taps-1 .. 1023] / 1024 (:156-158)
+        // keep y[n_taps-1 .. 1023] / 1024 (:156-158): the samples go through LDS so that the
+        // kept `block` of them leaves as consecutive 16-bit stores (128 B per wave instruction)
+        // whatever the alignment of this block in the output plane
         short *o = out + (size_t)f * plane + e * block;
         float *pc = precast ? precast + (size_t)f * plane + e * block : nullptr;
+        float *ys = reinterpret_cast<float *>(lds);                  // 1024 floats fit the wave's scratch
 #pragma unroll
-        for (int d = 0; d < 8; d++) {
-            const int i0 = 2 * lane + 128 * d - (n_taps - 1);
-            const float a = y[d].x * (1.0f / 1024.0f), b = y[d].y * (1.0f / 1024.0f);
-            if (i0 >= 0) { o[i0] = (short)cast_i16_bits(a); if (pc) pc[i0] = a; }
-            if (i0 + 1 >= 0) { o[i0 + 1] = (short)cast_i16_bits(b); if (pc) pc[i0 + 1] = b; }
+        for (int d = 0; d < 8; d++)
+            *reinterpret_cast<float2 *>(ys + 2 * lane + 128 * d) = make_float2(y[d].x * (1.0f / 1024.0f), y[d].y * (1.0f / 1024.0f));
+        wave_lds_fence();
+        for (int i = lane; i < block; i += 64) {
+            const float a = ys[i + n_taps - 1];
+            o[i] = (short)cast_i16_bits(a);
+            if (pc) pc[i] = a;
         }
+        wave_lds_fence();
     }
 }
 

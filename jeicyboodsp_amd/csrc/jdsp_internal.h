@@ -59,10 +59,11 @@ struct MvdrState {
 // Device-side view of one MFCC configuration (passed by value to the kernel).
 struct MfccDev {
     int win_len, hop, n_chan, n_cep, bin_stride;   // bin_stride 2: 512-point bins out of the 1024-point transform
+    int n_bins;
     float preemph;
     const float2 *window;        // [512] halved Hamming pairs over win_len, zero beyond
-    const int *mel_start, *mel_len;   // [64]
-    const float *mel_w;          // [max_len][64]
+    const float *mel_fb;         // [512] rgdFilterBank as float (zero beyond n_bins)
+    const int *mel_k;            // [512] rgdFiBins
     const double *dct;           // [n_chan][32]: sqrt(2/C) cos(PI i (k-0.5)/C)
     const double *lifter_w;      // [32]: 1 + L/2 sin(PI i / L)
 };

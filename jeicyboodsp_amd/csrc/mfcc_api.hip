@@ -49,27 +49,13 @@ int jdsp_mfcc_create(jdsp_ctx *ctx, const jdsp_mfcc_cfg *cfg, jdsp_mfcc **out)
                           : (h->mel_freqs[k] - fr) / (h->mel_freqs[k] - h->mel_freqs[k - 1]);
         h->fbank[i] = v < 0 ? 0 : v;
     }
-    // ---- MelFilterBank (:157-168) as per-channel contiguous bin ranges ----
-    std::vector<int> start(64, 0), len(64, 0);
-    int max_len = 1;
-    for (int ch = 0; ch < C; ch++) {
-        int lo = NB, hi = -1;
-        for (int i = 0; i < NB; i++) {
-            const int k = h->fi_bins[i];
-            const bool hit = (k == ch && k != C) || (k == ch + 1);
-            if (hit) { if (i < lo) lo = i; hi = i; }
-        }
-        if (hi >= lo) { start[ch] = lo; len[ch] = hi - lo + 1; if (len[ch] > max_len) max_len = len[ch]; }
+    // ---- per-bin filterbank weight and channel index for the kernel (MelFilterBank, :157-168) ----
+    std::vector<float> mel_fb(512, 0.f);
+    std::vector<int> mel_k(512, 0);
+    for (int i = 0; i < 512; i++) {
+        mel_fb[i] = i < NB ? (float)h->fbank[i] : 0.f;
+        mel_k[i] = i < NB ? h->fi_bins[i] : h->fi_bins[NB - 1];
     }
-    std::vector<float> mel_w((size_t)max_len * 64, 0.f);
-    for (int ch = 0; ch < C; ch++)
-        for (int t = 0; t < len[ch]; t++) {
-            const int i = start[ch] + t, k = h->fi_bins[i];
-            double w = 0.0;
-            if (k == ch + 1) w = h->fbank[i];                     // m[k-1] += fb * |X|        (:164)
-            else if (k == ch && k != C) w = 1 - h->fbank[i];      // m[k]   += (1-fb) * |X|    (:161,:166)
-            mel_w[(size_t)t * 64 + ch] = (float)w;
-        }
     // ---- DCT (:178-182) and lifter (:189) constants ----
     std::vector<double> dct((size_t)C * 32, 0.0), lift(32, 0.0);
     for (int i = 1; i <= c.n_cep; i++) {
@@ -84,14 +70,13 @@ int jdsp_mfcc_create(jdsp_ctx *ctx, const jdsp_mfcc_cfg *cfg, jdsp_mfcc **out)
         else window[i >> 1].x = (float)w;
     }
     // ---- one blob ----
-    const size_t o_win = 0, o_start = o_win + sizeof(float2) * 512, o_len = o_start + 64 * sizeof(int),
-                 o_w = o_len + 64 * sizeof(int), o_dct = (o_w + mel_w.size() * sizeof(float) + 15) / 16 * 16,
-                 o_lift = o_dct + dct.size() * sizeof(double), total = o_lift + 32 * sizeof(double);
+    const size_t o_win = 0, o_fb = o_win + sizeof(float2) * 512, o_k = o_fb + 512 * sizeof(float),
+                 o_dct = o_k + 512 * sizeof(int), o_lift = o_dct + dct.size() * sizeof(double),
+                 total = o_lift + 32 * sizeof(double);
     std::vector<char> host(total, 0);
     memcpy(&host[o_win], window.data(), sizeof(float2) * 512);
-    memcpy(&host[o_start], start.data(), 64 * sizeof(int));
-    memcpy(&host[o_len], len.data(), 64 * sizeof(int));
-    memcpy(&host[o_w], mel_w.data(), mel_w.size() * sizeof(float));
+    memcpy(&host[o_fb], mel_fb.data(), 512 * sizeof(float));
+    memcpy(&host[o_k], mel_k.data(), 512 * sizeof(int));
     memcpy(&host[o_dct], dct.data(), dct.size() * sizeof(double));
     memcpy(&host[o_lift], lift.data(), 32 * sizeof(double));
     hipError_t e = hipMalloc(&h->blob, total);
@@ -105,9 +90,9 @@ int jdsp_mfcc_create(jdsp_ctx *ctx, const jdsp_mfcc_cfg *cfg, jdsp_mfcc **out)
     h->dev.bin_stride = c.n_fft == 512 ? 2 : 1;
     h->dev.preemph = (float)c.preemph;
     h->dev.window = (const float2 *)(b + o_win);
-    h->dev.mel_start = (const int *)(b + o_start);
-    h->dev.mel_len = (const int *)(b + o_len);
-    h->dev.mel_w = (const float *)(b + o_w);
+    h->dev.n_bins = NB;
+    h->dev.mel_fb = (const float *)(b + o_fb);
+    h->dev.mel_k = (const int *)(b + o_k);
     h->dev.dct = (const double *)(b + o_dct);
     h->dev.lifter_w = (const double *)(b + o_lift);
     *out = h;

@@ -31,17 +31,33 @@ __global__ __launch_bounds__(64) void mfcc_kernel(const short *__restrict__ pcm,
 
     // x[i] = s[i] - preemph * s[i-1] for 1 <= i < win_len, x[0] = 0 (:208 starts at i = 1), zero beyond
     float2 v[8];
+    if (p.win_len == 1024 && (((uintptr_t)src) & 3u) == 0) {
+        // full-length window, 4-byte aligned frame: one dword per sample pair, plus the dword in
+        // front of it for the sample the pre-emphasis reaches back to
+        const unsigned int *s32 = reinterpret_cast<const unsigned int *>(src) + lane;
 #pragma unroll
-    for (int r = 0; r < 8; r++) {
-        const int i0 = 2 * lane + 128 * r;
-        float sm = 0.f, s0 = 0.f, s1 = 0.f;
-        if (i0 >= 1 && i0 - 1 < p.win_len) sm = (float)src[i0 - 1];
-        if (i0 < p.win_len) s0 = (float)src[i0];
-        if (i0 + 1 < p.win_len) s1 = (float)src[i0 + 1];
-        const float2 w = p.window[lane + 64 * r];            // halved Hamming pair, zero beyond win_len
-        float x0 = (i0 >= 1) ? s0 - p.preemph * sm : 0.f;
-        float x1 = s1 - p.preemph * s0;
-        v[r] = make_float2(x0 * w.x, x1 * w.y);
+        for (int r = 0; r < 8; r++) {
+            const float2 cur = unpack_i16x2(s32[64 * r]);
+            const bool first = (lane == 0 && r == 0);
+            const float sm = first ? 0.f : (float)((int)s32[first ? 0 : 64 * r - 1] >> 16);
+            const float2 w = p.window[lane + 64 * r];
+            const float x0 = first ? 0.f : cur.x - p.preemph * sm;
+            const float x1 = cur.y - p.preemph * cur.x;
+            v[r] = make_float2(x0 * w.x, x1 * w.y);
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const int i0 = 2 * lane + 128 * r;
+            float sm = 0.f, s0 = 0.f, s1 = 0.f;
+            if (i0 >= 1 && i0 - 1 < p.win_len) sm = (float)src[i0 - 1];
+            if (i0 < p.win_len) s0 = (float)src[i0];
+            if (i0 + 1 < p.win_len) s1 = (float)src[i0 + 1];
+            const float2 w = p.window[lane + 64 * r];            // halved Hamming pair, zero beyond win_len
+            float x0 = (i0 >= 1) ? s0 - p.preemph * sm : 0.f;
+            float x1 = s1 - p.preemph * s0;
+            v[r] = make_float2(x0 * w.x, x1 * w.y);
+        }
     }
     wave_fft512<false>(v, lds, lane, tw);
 #pragma unroll
@@ -65,20 +81,54 @@ __global__ __launch_bounds__(64) void mfcc_kernel(const short *__restrict__ pcm,
         else mag[m >> 1] = a0;                               // 512-point bins = even 1024-point bins
     }
     wave_lds_fence();
-    // mel filterbank: channel c sums bins [start[c], start[c]+len[c]) with the triangular
-    // weights MelFilterBank() applies in the same ascending-bin order (:157-168), then ln (:171)
-    if (lane < p.n_chan) {
-        const int st = p.mel_start[lane], ln = p.mel_len[lane];
-        float acc = 0.f;
-        for (int t = 0; t < ln; t++) acc += p.mel_w[t * 64 + lane] * mag[st + t];
-        logmel[lane] = logf(acc);
+    // mel filterbank (:157-168): every lane walks 8 CONSECUTIVE bins; consecutive bins feed the
+    // same one or two channels, so a lane sums them in registers and adds to the channel
+    // accumulators in LDS only when the channel index changes (2-4 LDS atomics per lane instead
+    // of a 90-iteration loop on the 38 lanes that own a channel)
+    logmel[lane] = 0.f;
+    wave_lds_fence();
+    {
+        const int i0 = 8 * lane;
+        if (i0 < p.n_bins) {
+            const float4 m0 = *reinterpret_cast<const float4 *>(&mag[i0]), m1 = *reinterpret_cast<const float4 *>(&mag[i0 + 4]);
+            const float4 f0 = *reinterpret_cast<const float4 *>(p.mel_fb + i0), f1 = *reinterpret_cast<const float4 *>(p.mel_fb + i0 + 4);
+            const int4 k0 = *reinterpret_cast<const int4 *>(p.mel_k + i0), k1 = *reinterpret_cast<const int4 *>(p.mel_k + i0 + 4);
+            const float mm[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
+            const float ff[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
+            const int kk[8] = {k0.x, k0.y, k0.z, k0.w, k1.x, k1.y, k1.z, k1.w};
+            int cur = kk[0];
+            float lo = 0.f, hi = 0.f;                      // partial sums for channels cur-1 and cur
+#pragma unroll
+            for (int t = 0; t < 8; t++) {
+                if (kk[t] != cur) {
+                    if (cur >= 1) atomicAdd(&logmel[cur - 1], lo);
+                    if (cur < p.n_chan) atomicAdd(&logmel[cur], hi);
+                    cur = kk[t];
+                    lo = hi = 0.f;
+                }
+                if (cur == 0) hi += (1.f - ff[t]) * mm[t];                 // :161
+                else {
+                    lo += ff[t] * mm[t];                                   // :164
+                    if (cur != p.n_chan) hi += (1.f - ff[t]) * mm[t];      // :165-166
+                }
+            }
+            if (cur >= 1) atomicAdd(&logmel[cur - 1], lo);
+            if (cur < p.n_chan) atomicAdd(&logmel[cur], hi);
+        }
     }
+    wave_lds_fence();
+    if (lane < p.n_chan) logmel[lane] = logf(logmel[lane]);               // :171
     wave_lds_fence();
     // DCT-II (:178-182) and lifter (:189)
     if (lane < p.n_cep) {
-        double acc = 0.0;
-        for (int k = 0; k < p.n_chan; k++) acc += p.dct[k * 32 + lane] * (double)logmel[k];
-        feats[f * p.n_cep + lane] = acc * p.lifter_w[lane];
+        double c0 = 0.0, c1 = 0.0;
+        int k = 0;
+        for (; k + 2 <= p.n_chan; k += 2) {
+            c0 += p.dct[k * 32 + lane] * (double)logmel[k];
+            c1 += p.dct[(k + 1) * 32 + lane] * (double)logmel[k + 1];
+        }
+        if (k < p.n_chan) c0 += p.dct[k * 32 + lane] * (double)logmel[k];
+        feats[f * p.n_cep + lane] = (c0 + c1) * p.lifter_w[lane];
     }
 }
 

@@ -62,6 +62,18 @@ def test_stft_generic_hop(eng, oracle, hop):
     _check(got.astype(np.complex128), oracle.stft(pcm, n_frames, 1024, hop))
 
 
+def test_stft_unaligned_device_buffer_takes_the_generic_path(eng, oracle):
+    """hop 512 but a PCM pointer that is not 16-byte aligned: results must not change."""
+    import torch
+    n_frames = 33
+    pcm = _pcm(77, 512 * (n_frames + 1) + 8)
+    d = torch.from_numpy(pcm).cuda()
+    for off in (1, 3, 4):                                            # 2, 6, 8 bytes off
+        got = eng.stft(d[off: off + 512 * (n_frames + 1)], n_frames)
+        torch.cuda.synchronize()
+        _check(got.cpu().numpy().astype(np.complex128), oracle.stft(pcm[off:], n_frames))
+
+
 def test_stft_edge_inputs(eng, oracle):
     assert eng.stft(np.zeros(1000, np.int16)).shape == (0, 1024)      # shorter than one frame
     z = eng.stft(np.zeros(2048, np.int16))
