@@ -90,8 +90,10 @@ int jdsp_fft_process_f64_dev(jdsp_ctx *ctx, const double *in_dev, double *out_de
  * (== WienerFilter_final.cpp:181-193, noise path SS:168-180): frame f =
  * pcm[hop*f .. hop*f+n_fft) * (0.54-0.46cos(2*3.141592*i/(n_fft-1))) -> unnormalised
  * forward DFT, all n_fft bins.  pcm must hold hop*(n_frames-1)+n_fft samples.
- * Supported: n_fft = 1024 with hop = 512 (reference-native, the headline
- * configuration) and any hop >= 1 for n_fft = 1024. */
+ * Supported: n_fft = 1024 with hop = 512 (reference-native, the headline configuration: pcm
+ * 16-byte aligned takes the fast kernel), n_fft = 1024 with any hop >= 1, and n_fft = 512 with
+ * any hop (BASELINE config 3 as written; computed as the even bins of the zero-padded
+ * 1024-point transform). */
 int jdsp_stft_i16_dev(jdsp_ctx *ctx, const int16_t *pcm_dev, long n_frames,
                       int n_fft, int hop, jdsp_c32 *spec_dev);
 int jdsp_stft_i16(jdsp_ctx *ctx, const int16_t *pcm_host, long n_samples,

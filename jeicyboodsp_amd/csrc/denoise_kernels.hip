@@ -25,40 +25,55 @@ namespace jdsp {
 // A11.  frame = [zeros(512), block] because the keep buffer is never updated (SS:154 is
 // unreachable); s = (short)(x * w) truncates; E = sum s^2 / 1024; Z counts s[i]*x[i+1] < 0
 // (the next sample is not windowed yet, SS:139).  E > 700 <=> sum s^2 > 716800 exactly.
+constexpr int kVadBlocksPerWave = 8;     // the FP64 window slice (64 B per lane) is loaded once per wave
+
 __global__ __launch_bounds__(64) void vad_kernel(const short *__restrict__ pcm, long n_blocks,
                                                  const double *__restrict__ w_hi, int use_zcr,
                                                  unsigned char *__restrict__ flags,
                                                  long long *__restrict__ dbg_energy, int *__restrict__ dbg_zcr)
 {
-    const long b = blockIdx.x;
     const int lane = threadIdx.x;
-    if (b >= n_blocks) return;
-    const u32x4 img = reinterpret_cast<const u32x4 *>(pcm + b * 512)[lane];
-    int x[9];
-    x[0] = (short)(img.x & 0xffffu); x[1] = (int)img.x >> 16;
-    x[2] = (short)(img.y & 0xffffu); x[3] = (int)img.y >> 16;
-    x[4] = (short)(img.z & 0xffffu); x[5] = (int)img.z >> 16;
-    x[6] = (short)(img.w & 0xffffu); x[7] = (int)img.w >> 16;
-    x[8] = __shfl_down(x[0], 1);                   // first sample of the next lane
-    if (lane == 63) x[8] = 0;                      // block sample 512 does not exist: frame[1024], defined 0
-    long long e = 0;
-    int z = 0;
+    const long b0 = (long)blockIdx.x * kVadBlocksPerWave;
+    if (b0 >= n_blocks) return;
+    double w[8];
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
-        const int s = (int)((double)x[k] * w_hi[8 * lane + k]);     // (short)(short * double), in range
-        e += (long long)s * s;
-        z += (s * x[k + 1] < 0) ? 1 : 0;
+    for (int k = 0; k < 8; k++) w[k] = w_hi[8 * lane + k];
+    u32x4 img[kVadBlocksPerWave];
+#pragma unroll
+    for (int i = 0; i < kVadBlocksPerWave; i++) {
+        const long b = b0 + i < n_blocks ? b0 + i : n_blocks - 1;
+        img[i] = reinterpret_cast<const u32x4 *>(pcm + b * 512)[lane];
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        e += __shfl_xor(e, o);
-        z += __shfl_xor(z, o);
-    }
-    if (lane == 0) {
-        // SS:147 with THRESHOLD_OF_ENERGY 700, _ZCR 200; BeamForming_MVDR_ver1.cpp:233 tests the energy only
-        flags[b] = (e > 716800LL || (use_zcr && z < 200)) ? 1 : 0;
-        if (dbg_energy) dbg_energy[b] = e;
-        if (dbg_zcr) dbg_zcr[b] = z;
+    for (int i = 0; i < kVadBlocksPerWave; i++) {
+        const long b = b0 + i;
+        if (b >= n_blocks) break;
+        int x[9];
+        x[0] = (short)(img[i].x & 0xffffu); x[1] = (int)img[i].x >> 16;
+        x[2] = (short)(img[i].y & 0xffffu); x[3] = (int)img[i].y >> 16;
+        x[4] = (short)(img[i].z & 0xffffu); x[5] = (int)img[i].z >> 16;
+        x[6] = (short)(img[i].w & 0xffffu); x[7] = (int)img[i].w >> 16;
+        x[8] = __shfl_down(x[0], 1);                   // first sample of the next lane
+        if (lane == 63) x[8] = 0;                      // block sample 512 does not exist: frame[1024], defined 0
+        long long e = 0;
+        int z = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int s = (int)((double)x[k] * w[k]);  // (short)(short * double), in range
+            e += (long long)s * s;
+            z += (s * x[k + 1] < 0) ? 1 : 0;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            e += __shfl_xor(e, o);
+            z += __shfl_xor(z, o);
+        }
+        if (lane == 0) {
+            // SS:147 with THRESHOLD_OF_ENERGY 700, _ZCR 200; BeamForming_MVDR_ver1.cpp:233 tests the energy only
+            flags[b] = (e > 716800LL || (use_zcr && z < 200)) ? 1 : 0;
+            if (dbg_energy) dbg_energy[b] = e;
+            if (dbg_zcr) dbg_zcr[b] = z;
+        }
     }
 }
 
@@ -594,7 +609,8 @@ int launch_vad(hipStream_t s, const short *pcm, long n_blocks, const double *w_h
                long long *dbg_energy, int *dbg_zcr)
 {
     if (n_blocks <= 0) return 0;
-    hipLaunchKernelGGL(vad_kernel, dim3((unsigned)n_blocks), dim3(64), 0, s, pcm, n_blocks, w_hi, use_zcr, flags,
+    hipLaunchKernelGGL(vad_kernel, dim3((unsigned)((n_blocks + kVadBlocksPerWave - 1) / kVadBlocksPerWave)), dim3(64), 0,
+                       s, pcm, n_blocks, w_hi, use_zcr, flags,
                        dbg_energy, dbg_zcr);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }

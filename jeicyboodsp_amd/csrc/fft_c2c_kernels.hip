@@ -41,8 +41,10 @@ __global__ __launch_bounds__(256) void fft_process_f64_kernel(const double2 *__r
     double2 *x = reinterpret_cast<double2 *>(smem_raw);
     const double2 *src = in + (size_t)blockIdx.x * n_fft;
     double2 *dst = out + (size_t)blockIdx.x * n_fft;
+    // Bitrev gather (:204-205), done as a coalesced read + scattered LDS write: the table is an
+    // involution for n_fft = 2^log2n, so x[rev[k]] = src[k] is the same permutation
     for (int k = threadIdx.x; k < n_fft; k += blockDim.x)
-        x[k] = src[(unsigned short)bitrev16(k, log2n, n_fft)];      // Bitrev gather (:204-205)
+        x[(unsigned short)bitrev16(k, log2n, n_fft)] = src[k];
     __syncthreads();
     const int half_n = n_fft >> 1;
     for (int s = 0; s < log2n; s++) {

@@ -89,6 +89,7 @@ int jdsp_destroy(jdsp_ctx *ctx)
     for (auto &p : ctx->c2c_tw)
         if (p) (void)hipFree(p);
     if (ctx->vad_w_hi) (void)hipFree(ctx->vad_w_hi);
+    if (ctx->win512) (void)hipFree(ctx->win512);
     if (ctx->conv_tw4096) (void)hipFree(ctx->conv_tw4096);
     if (ctx->conv_tw8192) (void)hipFree(ctx->conv_tw8192);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -305,7 +306,7 @@ int jdsp_pitch_autocorr(jdsp_ctx *ctx, const int16_t *pcm_host, long n_blocks, c
 int jdsp_stft_i16_dev(jdsp_ctx *ctx, const int16_t *pcm_dev, long n_frames, int n_fft, int hop, jdsp_c32 *spec_dev)
 {
     if (!ctx) return JDSP_EINVAL;
-    if (n_fft != 1024) return fail(ctx, JDSP_EINVAL, "jdsp_stft_i16_dev: n_fft must be 1024");
+    if (n_fft != 1024 && n_fft != 512) return fail(ctx, JDSP_EINVAL, "jdsp_stft_i16_dev: n_fft must be 1024 or 512");
     if (hop < 1) return fail(ctx, JDSP_EINVAL, "jdsp_stft_i16_dev: hop must be >= 1");
     if (n_frames < 0 || (n_frames > 0 && (!pcm_dev || !spec_dev)))
         return fail(ctx, JDSP_EINVAL, "jdsp_stft_i16_dev: bad buffer");
@@ -315,6 +316,18 @@ int jdsp_stft_i16_dev(jdsp_ctx *ctx, const int16_t *pcm_dev, long n_frames, int 
     JDSP_HIP(ctx, hipSetDevice(ctx->device));
     int rc = jdsp::ensure_stft1024_table(ctx);
     if (rc) return rc;
+    if (n_fft == 512) {
+        if (!ctx->win512) {
+            float2 w[256];
+            jdsp::fill_win512(w);
+            JDSP_HIP(ctx, hipMalloc((void **)&ctx->win512, sizeof(w)));
+            JDSP_HIP(ctx, hipMemcpy(ctx->win512, w, sizeof(w), hipMemcpyHostToDevice));
+        }
+        if (jdsp::launch_stft512(ctx->stream, ctx->n_cu, pcm_dev, n_frames, hop, (float2 *)spec_dev, ctx->stft1024_table,
+                                 ctx->win512))
+            return fail(ctx, JDSP_EHIP, "stft512 launch", hipGetLastError());
+        return JDSP_OK;
+    }
     if (jdsp::launch_stft1024(ctx->stream, ctx->n_cu, ctx->opt_stft_fpw, pcm_dev, n_frames, hop, (float2 *)spec_dev, ctx->stft1024_table))
         return fail(ctx, JDSP_EHIP, "stft1024 launch", hipGetLastError());
     return JDSP_OK;
@@ -324,7 +337,7 @@ int jdsp_stft_i16(jdsp_ctx *ctx, const int16_t *pcm_host, long n_samples, int n_
                   long *n_frames_out)
 {
     if (!ctx) return JDSP_EINVAL;
-    if (n_fft != 1024 || hop < 1) return fail(ctx, JDSP_EINVAL, "jdsp_stft_i16: unsupported n_fft/hop");
+    if ((n_fft != 1024 && n_fft != 512) || hop < 1) return fail(ctx, JDSP_EINVAL, "jdsp_stft_i16: unsupported n_fft/hop");
     long n_frames = n_samples >= n_fft ? (n_samples - n_fft) / hop + 1 : 0;
     if (n_frames_out) *n_frames_out = n_frames;
     if (n_frames == 0) return JDSP_OK;

@@ -22,6 +22,7 @@ struct jdsp_ctx {
     int opt_stft_fpw = 0;              // 0 = auto
     // device tables, created on first use
     float2 *stft1024_table = nullptr;
+    float2 *win512 = nullptr;          // halved Hamming-512 pairs
     double2 *c2c_tw[16] = {nullptr};   // by log2(n_fft)
     float2 *conv_tw4096 = nullptr, *conv_tw8192 = nullptr;
     double *vad_w_hi = nullptr;        // second half of the FP64 Hamming window
@@ -82,6 +83,10 @@ void fill_stft1024_table(float2 *host_table);
 int launch_stft1024(hipStream_t stream, int n_cu, int fpw_opt, const short *pcm, long n_frames, long hop, float2 *spec,
                     const float2 *table);
 
+
+int launch_stft512(hipStream_t stream, int n_cu, const short *pcm, long n_frames, long hop, float2 *spec,
+                   const float2 *table, const float2 *win512);
+void fill_win512(float2 *w);
 
 // fft_c2c_kernels.hip
 int launch_bitrev_table(hipStream_t stream, short *table_dev, int n_fft, int bits);

@@ -181,6 +181,84 @@ __global__ __launch_bounds__(64) void stft1024_anyhop_kernel(const short *__rest
     }
 }
 
+// n_fft = 512 (BASELINE config 3 as written; the reference's SS/Wiener use 1024): the 512-point
+// spectrum of a frame is exactly the even bins of the 1024-point spectrum of the frame
+// zero-padded, so the same wave transform serves; only the even half of the split is formed.
+template <int J>
+__device__ __forceinline__ void split_store_even_j(const float2 *lds, int lane, float2 wsp0, float2 *dst)
+{
+    const int m = 128 * J + 2 * lane;
+    const float2 zm = lds[m];
+    const float2 zr = lds[(512 - m) & 511];
+    float2 lo, hi;
+    split_fwd<J>(zm, zr, wsp0, lo, hi);
+    __builtin_nontemporal_store(lo.x, &dst[64 * J + lane].x);
+    __builtin_nontemporal_store(lo.y, &dst[64 * J + lane].y);
+    __builtin_nontemporal_store(hi.x, &dst[256 + 64 * J + lane].x);
+    __builtin_nontemporal_store(hi.y, &dst[256 + 64 * J + lane].y);
+}
+
+__global__ __launch_bounds__(64) void stft512_kernel(const short *__restrict__ pcm, float2 *__restrict__ spec,
+                                                     long n_frames, int frames_per_wave, long hop,
+                                                     const float2 *__restrict__ table,
+                                                     const float2 *__restrict__ win512)
+{
+    __shared__ __attribute__((aligned(16))) float2 lds[kWaveLdsComplex];
+    const int lane = threadIdx.x;
+    const long f0 = (long)blockIdx.x * frames_per_wave;
+    long f1 = f0 + frames_per_wave;
+    if (f1 > n_frames) f1 = n_frames;
+    if (f0 >= f1) return;
+    WaveTwiddles tw;
+    load_wave_twiddles(tw, table, lane);
+    const float2 wsp0 = table[kStftSplit + 2 * lane];
+    float2 win[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) win[r] = win512[lane + 64 * r];
+    for (long f = f0; f < f1; f++) {
+        float2 v[8];
+        const short *src = pcm + f * hop + 2 * lane;
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+            v[r] = make_float2((float)src[128 * r] * win[r].x, (float)src[128 * r + 1] * win[r].y);
+#pragma unroll
+        for (int r = 4; r < 8; r++) v[r] = make_float2(0.f, 0.f);
+        wave_fft512<false>(v, lds, lane, tw);
+#pragma unroll
+        for (int d = 0; d < 8; d++) lds[lane + 64 * d] = v[d];
+        wave_lds_fence();
+        float2 *dst = spec + f * 512;
+        split_store_even_j<0>(lds, lane, wsp0, dst);
+        split_store_even_j<1>(lds, lane, wsp0, dst);
+        split_store_even_j<2>(lds, lane, wsp0, dst);
+        split_store_even_j<3>(lds, lane, wsp0, dst);
+        wave_lds_fence();
+    }
+}
+
+int launch_stft512(hipStream_t stream, int n_cu, const short *pcm, long n_frames, long hop, float2 *spec,
+                   const float2 *table, const float2 *win512)
+{
+    if (n_frames <= 0) return 0;
+    long target_waves = (long)n_cu * 32;
+    long fpw = (n_frames + target_waves - 1) / target_waves;
+    if (fpw > 8) fpw = 8;
+    if (fpw < 1) fpw = 1;
+    const long grid = (n_frames + fpw - 1) / fpw;
+    hipLaunchKernelGGL(stft512_kernel, dim3((unsigned)grid), dim3(64), 0, stream, pcm, spec, n_frames, (int)fpw, hop,
+                       table, win512);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+void fill_win512(float2 *w)
+{
+    for (int i = 0; i < 256; i++) {
+        const double w0 = (0.54 - 0.46 * cos(2 * 3.141592 * (2 * i) / (512 - 1)));
+        const double w1 = (0.54 - 0.46 * cos(2 * 3.141592 * (2 * i + 1) / (512 - 1)));
+        w[i] = make_float2((float)(0.5 * w0), (float)(0.5 * w1));
+    }
+}
+
 template <int K>
 static void launch_hop512(hipStream_t stream, const short *pcm, long n_frames, float2 *spec, const float2 *table)
 {

@@ -74,6 +74,16 @@ def test_stft_unaligned_device_buffer_takes_the_generic_path(eng, oracle):
         _check(got.cpu().numpy().astype(np.complex128), oracle.stft(pcm[off:], n_frames))
 
 
+@pytest.mark.parametrize("hop", [256, 512, 100])
+def test_stft_512_point_frames(eng, oracle, hop):
+    """BASELINE config 3 as written (512-pt STFT, 50 % hop) and other hops."""
+    n_frames = 70
+    pcm = _pcm(hop + 1, hop * (n_frames - 1) + 512)
+    got = eng.stft(pcm, n_fft=512, hop=hop)
+    assert got.shape == (n_frames, 512)
+    _check(got.astype(np.complex128), oracle.stft(pcm, n_frames, 512, hop))
+
+
 def test_stft_edge_inputs(eng, oracle):
     assert eng.stft(np.zeros(1000, np.int16)).shape == (0, 1024)      # shorter than one frame
     z = eng.stft(np.zeros(2048, np.int16))
