@@ -1,0 +1,81 @@
+"""GPU-box tests of the C ABI's error behaviour: bad arguments come back as negative codes
+with a message, never as a crash or a silent fallback."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import jeicyboodsp_amd
+    e = jeicyboodsp_amd.Engine(0)
+    yield e
+    e.close()
+
+
+def test_bad_sizes_and_alignment(eng):
+    import torch
+    from jeicyboodsp_amd import JdspError, _lib
+    L = _lib.lib
+    pcm = torch.zeros(4096, dtype=torch.int16, device="cuda")
+    spec = torch.empty((4, 1024), dtype=torch.complex64, device="cuda")
+    h = eng._h
+    assert L.jdsp_stft_i16_dev(h, C.c_void_p(pcm.data_ptr()), 4, 2048, 512, C.c_void_p(spec.data_ptr())) == _lib.EINVAL
+    assert b"n_fft" in L.jdsp_last_error(h)
+    assert L.jdsp_stft_i16_dev(h, C.c_void_p(pcm.data_ptr()), 4, 1024, 0, C.c_void_p(spec.data_ptr())) == _lib.EINVAL
+    assert L.jdsp_stft_i16_dev(h, None, 4, 1024, 512, C.c_void_p(spec.data_ptr())) == _lib.EINVAL
+    assert L.jdsp_stft_i16_dev(h, C.c_void_p(pcm.data_ptr()), 4, 1024, 512, C.c_void_p(spec.data_ptr() + 8)) == _lib.EINVAL
+    assert L.jdsp_stft_i16_dev(h, C.c_void_p(pcm.data_ptr()), 0, 1024, 512, None) == 0          # nothing to do
+    assert L.jdsp_set_option(h, b"no.such.option", 1) == _lib.EINVAL
+    with pytest.raises(JdspError):
+        eng.fft_process(np.zeros((2, 16384), np.complex128))        # > 8192
+    with pytest.raises(JdspError):
+        eng.denoiser(7)
+    with pytest.raises(JdspError):
+        eng.fastconv(np.ones(2000), 1024)                           # more taps than the transform
+    with pytest.raises(JdspError):
+        eng.fastconv(np.ones(10), 4096)                             # unsupported transform size
+    with pytest.raises(JdspError):
+        eng.mfcc(n_fft=256)
+    with pytest.raises(JdspError):
+        eng.mfcc(win_len=2000)
+    d = eng.denoiser(0)
+    bad = torch.zeros(512 * 3 + 8, dtype=torch.int16, device="cuda")[4:4 + 512 * 3]   # 8 bytes off
+    out = torch.empty(512, dtype=torch.int16, device="cuda")
+    assert L.jdsp_denoise_process_dev(d._h, C.c_void_p(bad.data_ptr()), 3, C.c_void_p(out.data_ptr()), None, None) == _lib.EINVAL
+    assert L.jdsp_denoise_process_dev(d._h, C.c_void_p(pcm.data_ptr()), -1, None, None, None) == _lib.EINVAL
+    assert L.jdsp_denoise_shard_vad_dev(d._h, C.c_void_p(pcm.data_ptr()), 5, 4, 8, 8, C.c_void_p(out.data_ptr())) == _lib.EINVAL
+    d.close()
+
+
+def test_zero_length_calls_are_ok(eng):
+    d = eng.denoiser(1)
+    assert d.process(np.zeros(0, np.int16)).size == 0
+    assert d.process(np.zeros(512, np.int16)).size == 0              # first block of a stream: nothing out
+    fc = eng.fastconv(np.ones(8), 1024)
+    assert fc.process(np.zeros(0, np.int16)).shape == (1, 0)
+    m = eng.mfcc()
+    assert m.frames(np.zeros(100, np.int16)).shape == (0, 12)
+    arg, rmax = eng.pitch(np.zeros(0, np.int16))
+    assert arg.size == 0
+    for o in (d, fc, m):
+        o.close()
+
+
+def test_two_handles_are_independent(eng):
+    """One handle per audio stream: interleaving two streams must not mix their state."""
+    rng = np.random.default_rng(0)
+    a = np.clip(np.rint(rng.normal(0, 3000, 20 * 512)), -32768, 32767).astype(np.int16)
+    b = np.clip(np.rint(rng.normal(0, 800, 20 * 512)), -32768, 32767).astype(np.int16)
+    da, db, ref_a, ref_b = eng.denoiser(1), eng.denoiser(1), eng.denoiser(1), eng.denoiser(1)
+    outs_a, outs_b = [], []
+    for k in range(0, 20, 5):
+        outs_a.append(da.process(a[k * 512:(k + 5) * 512]))
+        outs_b.append(db.process(b[k * 512:(k + 5) * 512]))
+    assert np.array_equal(np.concatenate(outs_a), ref_a.process(a))
+    assert np.array_equal(np.concatenate(outs_b), ref_b.process(b))
+    for o in (da, db, ref_a, ref_b):
+        o.close()

@@ -94,6 +94,23 @@ def main():
         ms = timed(lambda: m.frames(x16, B), a.iters)
         report("mfcc_400_160_512fft_40mel", ms, B, "frames", 320 + 104, 5 * 512 * 9 + 512 * 14, "BASELINE config 4 framing")
         m.close()
+    if on("mfcc10k"):
+        # BASELINE config 4: a 10,000-utterance batch (ragged, 1-6 s at 16 kHz), every utterance framed
+        # on its own; on N GPUs jeicyboodsp_amd.sharding.utterance_shard hands out whole utterances
+        from jeicyboodsp_amd import sharding
+        lens = rng.integers(16000, 96000, 10000)
+        m = eng.mfcc(win_len=400, hop=160, n_fft=512, n_chan=40, n_cep=13, half_rate=8000.0)
+        fpu = [(int(n) - 400) // 160 + 1 for n in lens]
+        offs = np.concatenate([[0], np.cumsum(lens)])
+        starts = np.concatenate([offs[u] + 160 * np.arange(fpu[u], dtype=np.int64) for u in range(len(lens))])
+        x = torch.from_numpy(pcm_of(rng, int(offs[-1]))).cuda()
+        st = torch.from_numpy(starts).cuda()
+        ms = timed(lambda: m.frames(x, len(starts), frame_start=st), max(a.iters // 4, 3))
+        loads = [sum(fpu[f:f + n]) for f, n in (sharding.utterance_shard(fpu, r, 8) for r in range(8))]
+        report("mfcc_10k_utterances_400_160_512fft_40mel", ms, len(starts), "frames", 320 + 104, 5 * 512 * 9 + 512 * 14,
+               "10,000 ragged utterances, %d frames; an 8-way utterance split is balanced to %.2f%%"
+               % (len(starts), 100.0 * (max(loads) - min(loads)) / max(loads)))
+        m.close()
     if on("fastconv"):
         nb = 4096
         taps = rng.normal(size=7169) * 0.01
