@@ -16,7 +16,9 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 import jeicyboodsp_amd  # noqa: E402
+import oracle_lib  # noqa: E402  (CPU checker: timed here as the per-chain CPU baseline, never used by the product)
 
 HBM_PEAK = 8000.0       # GB/s
 FP32_PEAK = 157.3       # TFLOP/s vector
@@ -37,6 +39,18 @@ def timed(fn, iters, rounds=5):
     return statistics.median(ts)
 
 
+def cpu_rate(fn, units):
+    """units/s of the CPU oracle (FP64, one thread, structured like the reference) on a bounded sample."""
+    import time
+    fn()
+    t0 = time.perf_counter()
+    n = 0
+    while time.perf_counter() - t0 < 1.5:
+        fn()
+        n += 1
+    return units * n / (time.perf_counter() - t0)
+
+
 def pcm_of(rng, n, sigma=3000.0):
     return np.clip(np.rint(rng.normal(0, sigma, n)), -32768, 32767).astype(np.int16)
 
@@ -47,16 +61,19 @@ def main():
     ap.add_argument("--only", default="")
     a = ap.parse_args()
     eng = jeicyboodsp_amd.Engine(0)
+    orc = oracle_lib.load_oracle()
     rng = np.random.default_rng(0)
     out = []
 
-    def report(name, ms, units, unit_name, bytes_per_unit, flops_per_unit, note=""):
+    def report(name, ms, units, unit_name, bytes_per_unit, flops_per_unit, note="", cpu=None):
         rate = units / (ms * 1e-3)
         gbs = rate * bytes_per_unit / 1e9
         tf = rate * flops_per_unit / 1e12
         line = {"chain": name, "ms": ms, "units": units, "unit": unit_name, "rate_per_s": rate,
                 "algorithmic_GBps": gbs, "hbm_frac": gbs / HBM_PEAK, "fft_TFLOPs": tf, "fp32_vector_frac": tf / FP32_PEAK,
                 "note": note}
+        if cpu is not None:
+            line["cpu_baseline"] = {"value": cpu, "unit": unit_name + "/s", "cores": 1, "kind": "port"}
         out.append(line)
         print(json.dumps(line), flush=True)
 
@@ -80,14 +97,17 @@ def main():
             ms = timed(step, a.iters)
             # 512 int16 in + 512 int16 out per block; forward + inverse 1024-pt real transforms
             report("denoise_" + nm, ms, B, "blocks", 2048, 2 * 5 * 512 * 9 + 2 * 512 * 14,
-                   "VAD + plan + noise estimate + fused window/FFT/gain/IFFT/OLA, 65,536 blocks of 512")
+                   "VAD + plan + noise estimate + fused window/FFT/gain/IFFT/OLA, 65,536 blocks of 512",
+                   cpu=cpu_rate(lambda: orc.denoise_stream(mode, x[:1024 * 512]), 1024))
             d.close()
     if on("mfcc"):
         x = torch.from_numpy(pcm_of(rng, 512 * (B + 1))).cuda()
         m = eng.mfcc()
         ms = timed(lambda: m.frames(x, B), a.iters)
+        xs = x[:512 * 257].cpu().numpy()
         report("mfcc_native_1024_512_38ch", ms, B, "frames", 1024 + 96, 5 * 512 * 9 + 512 * 14 + 2 * 1024 + 2 * 38 * 12,
-               "pre-emphasis/Hamming/FFT/mel/ln/DCT/lifter, 65,536 frames, 12 doubles out")
+               "pre-emphasis/Hamming/FFT/mel/ln/DCT/lifter, 65,536 frames, 12 doubles out",
+               cpu=cpu_rate(lambda: orc.mfcc_frames(orc.mfcc_native_cfg(), xs, 256), 256))
         m.close()
         x16 = torch.from_numpy(pcm_of(rng, 160 * (B - 1) + 400)).cuda()
         m = eng.mfcc(win_len=400, hop=160, n_fft=512, n_chan=40, n_cep=13, half_rate=8000.0)
@@ -121,8 +141,10 @@ def main():
             fc.reset()
             fc.process(x)
         ms = timed(step, max(a.iters // 4, 3))
+        xs = x[:71 * 1024].cpu().numpy()
         report("fastconv_8192_native", ms, nb - 7, "blocks", 4096, 2 * 5 * 4096 * 12 + 2 * 4096 * 14 + 8192 * 6,
-               "reference-native: 7169 taps, 1024-sample blocks, one 512-thread workgroup per block")
+               "reference-native: 7169 taps, 1024-sample blocks, one 512-thread workgroup per block",
+               cpu=cpu_rate(lambda: orc.fastconv_stream(xs, taps, 8192), 64))
         fc.close()
         nb = 65536
         h2 = rng.normal(size=(2, 256)) * 0.1
@@ -133,14 +155,41 @@ def main():
             fc.reset()
             fc.process(x)
         ms = timed(step2, a.iters)
+        xs = x[:513 * 769].cpu().numpy()
         report("fastconv_1024_hrir_pair", ms, nb - 1, "blocks", 4614, 3 * 5 * 512 * 9 + 3 * 512 * 14 + 2 * 1024 * 6,
-               "BASELINE config 2: 256-tap pair, 769-sample blocks, mono in -> 2 ears out")
+               "BASELINE config 2: 256-tap pair, 769-sample blocks, mono in -> 2 ears out",
+               cpu=cpu_rate(lambda: [orc.fastconv_stream(xs, h2[0], 1024), orc.fastconv_stream(xs, h2[1], 1024)], 512))
         fc.close()
     if on("fft"):
         n = 65536
         z = torch.from_numpy(rng.normal(size=(n, 512)) + 1j * rng.normal(size=(n, 512))).cuda()
         ms = timed(lambda: eng.fft_process(z), max(a.iters // 4, 3))
-        report("fftprocess_f64_512", ms, n, "transforms", 2 * 512 * 16, 5 * 512 * 9, "FFTAlgorithm_ver2 FFTProcess, FP64, batch 65,536")
+        zs = z[:256].cpu().numpy()
+        report("fftprocess_f64_512", ms, n, "transforms", 2 * 512 * 16, 5 * 512 * 9, "FFTAlgorithm_ver2 FFTProcess, FP64, batch 65,536",
+               cpu=cpu_rate(lambda: orc.fft_process(zs), 256))
+    if on("pitch"):
+        x = pcm_of(rng, B * 512)
+        t = torch.from_numpy(x).cuda()
+        ms = timed(lambda: eng.pitch(t), a.iters)
+        report("pitch_autocorr", ms, B, "blocks", 1024 + 8, 2 * 5 * 512 * 9 + 2 * 512 * 14,
+               "PitchEstimation_method1 CalcPitch: FFT -> |X|^2 -> IFFT -> arg max, 65,536 blocks",
+               cpu=cpu_rate(lambda: orc.pitch_stream(x[:1024 * 512]), 1024))
+    if on("mvdr"):
+        l = pcm_of(rng, B * 512)
+        r = pcm_of(rng, B * 512)
+        l[:12 * 512] = pcm_of(rng, 12 * 512, 45.0)
+        tl, tr = torch.from_numpy(l).cuda(), torch.from_numpy(r).cuda()
+        mv = eng.mvdr(0.0)
+        mv.process(tl, tr)
+
+        def stepm():
+            mv.reset()
+            mv.process(tl, tr)
+        ms = timed(stepm, a.iters)
+        report("mvdr_2mic", ms, B, "blocks", 3072, 3 * 5 * 512 * 9 + 3 * 512 * 14 + 1024 * 40,
+               "BeamForming_MVDR_ver1: VAD + correlation + per-bin weights + inverse, 65,536 stereo blocks",
+               cpu=cpu_rate(lambda: orc.mvdr_stream(l[:512 * 512], r[:512 * 512]), 512))
+        mv.close()
     eng.close()
 
 
