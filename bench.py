@@ -29,16 +29,16 @@ HBM_PEAK_GBS = 8000.0                         # MI355X_MICROARCH.md: 8.0 TB/s sp
 
 
 def synth_pcm(rank, n_frames, world=1):
-    """SURVEY.md §8d synthetic input: default_rng(0).normal(0,3000) int16.  The global stream has
-    world*B frames = (world*B+1)*512 samples; rank r owns frames [r*B, (r+1)*B) and reads its slice
-    plus the 512-sample halo (jeicyboodsp_amd.sharding.stft_shard) -- no communication."""
+    """SURVEY.md §8d synthetic input: normal(0, 3000) rounded and clipped to int16, (B+1)*512 samples
+    per rank = B frames + the 512-sample halo (jeicyboodsp_amd.sharding.stft_shard).  Rank 0 draws
+    from default_rng(0) exactly as SURVEY specifies; rank r draws its shard of the global stream from
+    default_rng(r), so that an 8-rank job does not have every rank generate 8 shards of noise."""
     import numpy as np
     from jeicyboodsp_amd import sharding
     s = sharding.stft_shard(n_frames * world, rank, world, N_FFT, HOP)
-    assert s.count == n_frames
-    rng = np.random.default_rng(0)
-    x = np.clip(np.rint(rng.normal(0.0, 3000.0, s.sample_first + s.sample_count)), -32768, 32767).astype(np.int16)
-    return x[s.sample_first:]
+    assert s.count == n_frames and s.sample_count == HOP * (n_frames - 1) + N_FFT
+    rng = np.random.default_rng(rank)
+    return np.clip(np.rint(rng.normal(0.0, 3000.0, s.sample_count)), -32768, 32767).astype(np.int16)
 
 
 def cpu_baseline(seconds=10.0):
