@@ -184,6 +184,11 @@ int jdsp_fastconv_create(jdsp_ctx *ctx, const double *taps, int n_taps, int n_fi
                          jdsp_fastconv **out);
 int jdsp_fastconv_destroy(jdsp_fastconv *h);
 int jdsp_fastconv_reset(jdsp_fastconv *h);
+/* Multi-GPU / random access: pretend `blocks_consumed` blocks of the stream have already been
+ * processed (history = silence).  A rank that owns output blocks [e0, e1) of a stream feeds
+ * input blocks [e0 + hist_blocks - hist_blocks', ...): see sharding.fastconv_sharded -- it
+ * prepends hist_blocks halo blocks and drops the outputs they produce. */
+int jdsp_fastconv_set_position(jdsp_fastconv *h, long blocks_consumed);
 int jdsp_fastconv_block_len(const jdsp_fastconv *h);
 int jdsp_fastconv_hist_blocks(const jdsp_fastconv *h);
 long jdsp_fastconv_blocks_out(const jdsp_fastconv *h, long n_blocks);

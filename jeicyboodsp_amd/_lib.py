@@ -75,6 +75,7 @@ def _load():
         "jdsp_fastconv_create": (i, [vp, vp, i, i, i, C.POINTER(vp)]),
         "jdsp_fastconv_destroy": (i, [vp]),
         "jdsp_fastconv_reset": (i, [vp]),
+        "jdsp_fastconv_set_position": (i, [vp, l]),
         "jdsp_fastconv_block_len": (i, [vp]),
         "jdsp_fastconv_hist_blocks": (i, [vp]),
         "jdsp_fastconv_blocks_out": (l, [vp, l]),

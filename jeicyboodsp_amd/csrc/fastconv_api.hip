@@ -80,6 +80,15 @@ int jdsp_fastconv_reset(jdsp_fastconv *h)
     return JDSP_OK;
 }
 
+int jdsp_fastconv_set_position(jdsp_fastconv *h, long blocks_consumed)
+{
+    if (!h || blocks_consumed < 0) return JDSP_EINVAL;
+    int rc = jdsp_fastconv_reset(h);                 // history = silence; the caller feeds the halo blocks itself
+    if (rc) return rc;
+    h->calls = blocks_consumed;
+    return JDSP_OK;
+}
+
 int jdsp_fastconv_block_len(const jdsp_fastconv *h) { return h ? h->block : 0; }
 int jdsp_fastconv_hist_blocks(const jdsp_fastconv *h) { return h ? h->n_hist : 0; }
 

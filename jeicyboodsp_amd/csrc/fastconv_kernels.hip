@@ -164,7 +164,10 @@ __device__ __forceinline__ void wg_fft4096(float2 (&v)[8], float2 *rows, int t, 
 
 __device__ __forceinline__ float2 row_at(const float2 *rows, int k) { return rows[(k & 7) * kRow + (k >> 3)]; }
 
-__global__ __launch_bounds__(512) void fastconv8192_kernel(ConvStream s, long n_out_blocks, int first_block, int block,
+#ifndef JDSP_CONV8192_MINWAVES
+#define JDSP_CONV8192_MINWAVES 2
+#endif
+__global__ __launch_bounds__(512, JDSP_CONV8192_MINWAVES) void fastconv8192_kernel(ConvStream s, long n_out_blocks, int first_block, int block,
                                                            int n_taps, int n_filters, const float2 *__restrict__ Hall,
                                                            const float2 *__restrict__ table,
                                                            const float2 *__restrict__ tw4096,

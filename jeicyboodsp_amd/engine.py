@@ -367,6 +367,9 @@ class FastConv:
     def reset(self):
         self.eng._ck(L.jdsp_fastconv_reset(self._h))
 
+    def set_position(self, blocks_consumed):
+        self.eng._ck(L.jdsp_fastconv_set_position(self._h, int(blocks_consumed)))
+
     def blocks_out(self, n_blocks):
         return L.jdsp_fastconv_blocks_out(self._h, n_blocks)
 

@@ -101,3 +101,29 @@ def denoise_sharded(denoiser, pcm_ext, ext0, b0, b1, n_total, rank, world, gathe
     last = denoiser.shard_rows(summaries, world, rank)
     lasts = gather(last.reshape(1, -1), [1] * world).contiguous()
     return denoiser.shard_finish(lasts, world, rank)
+
+
+def fastconv_shard_blocks(n_blocks, hist_blocks, rank, world):
+    """Input blocks a rank must be given to produce its share of an overlap-save stream.
+    The stream of n_blocks input blocks emits n_blocks - hist_blocks output blocks (the first
+    hist_blocks inputs only prime the history); emitted block e is input block e + hist_blocks.
+    Returns (first_input_block, n_input_blocks, first_emitted, n_emitted): the rank reads
+    hist_blocks halo blocks in front of its own."""
+    n_out = max(n_blocks - hist_blocks, 0)
+    e0, cnt = split_even(n_out, rank, world)
+    if cnt == 0:
+        return e0, 0, e0, 0
+    return e0, cnt + hist_blocks, e0, cnt
+
+
+def fastconv_sharded(conv, pcm, n_blocks, rank, world):
+    """One rank's emitted blocks of conv applied to the whole stream `pcm` (int16 tensor/array the
+    rank can slice: only its own blocks plus the halo are touched).  [n_filters, n_emitted*block]."""
+    first_in, n_in, e0, cnt = fastconv_shard_blocks(n_blocks, conv.hist_blocks, rank, world)
+    if cnt == 0:
+        return None
+    conv.set_position(first_in)
+    out = conv.process(pcm[first_in * conv.block:(first_in + n_in) * conv.block])
+    # position first_in >= hist_blocks: every fed block emits; the first hist_blocks of them saw a silent history
+    drop = out.shape[1] - cnt * conv.block
+    return out[:, drop:]
