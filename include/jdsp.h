@@ -228,6 +228,18 @@ int jdsp_mvdr_process_dev(jdsp_mvdr *h, const int16_t *left_dev, const int16_t *
 int jdsp_mvdr_process(jdsp_mvdr *h, const int16_t *left_host, const int16_t *right_host, long n_blocks,
                       int16_t *out_host, float *precast_host, long *n_out_blocks);
 int jdsp_mvdr_corr(jdsp_mvdr *h, double *corr4_host);
+/* Sharded MVDR (multi-GPU): the rank owns global blocks [b0, b1) of a stream of n_total
+ * blocks; the ext buffers hold global blocks [ext0, b1), ext0 = max(b0 - 1, 0).  shard_vad ->
+ * flags_own; all-gather -> flags_all; shard_summary -> sum4 (this rank's contribution to
+ * rgdSpatialCorr); all-gather -> sums_all (world*4 doubles); shard_finish -> the emitted blocks
+ * among [max(b0,1), b1).  rgdSpatialCorr is a running SUM (:263-268), so the matrix entering a
+ * rank is the sum of the earlier ranks' contributions: the reduction SURVEY §8e asks for. */
+int jdsp_mvdr_shard_vad_dev(jdsp_mvdr *h, const int16_t *left_ext_dev, const int16_t *right_ext_dev, long ext0, long b0,
+                            long b1, long n_total, uint8_t *flags_own_dev);
+int jdsp_mvdr_shard_summary_dev(jdsp_mvdr *h, const uint8_t *flags_all_dev, double *sum4_dev);
+long jdsp_mvdr_shard_blocks_out(const jdsp_mvdr *h);
+int jdsp_mvdr_shard_finish_dev(jdsp_mvdr *h, const double *sums_all_dev, int world, int rank, int16_t *out_dev,
+                               float *precast_dev, long *n_out_blocks);
 
 /* ---- MFCC ---------------------------------------------------------------------- */
 /* MFCCFeatureExtraction_auto_version1.cpp.  The #defines at :23-33 become a runtime

@@ -97,6 +97,10 @@ def _load():
         "jdsp_denoise_shard_rows_dev": (i, [vp, vp, i, i, vp]),
         "jdsp_denoise_shard_blocks_out": (l, [vp]),
         "jdsp_denoise_shard_finish_dev": (i, [vp, vp, i, i, vp, vp, C.POINTER(l)]),
+        "jdsp_mvdr_shard_vad_dev": (i, [vp, vp, vp, l, l, l, l, vp]),
+        "jdsp_mvdr_shard_summary_dev": (i, [vp, vp, vp]),
+        "jdsp_mvdr_shard_blocks_out": (l, [vp]),
+        "jdsp_mvdr_shard_finish_dev": (i, [vp, vp, i, i, vp, vp, C.POINTER(l)]),
         "jdsp_stft_i16_dev": (i, [vp, vp, l, i, i, vp]),
         "jdsp_stft_i16": (i, [vp, vp, l, i, i, vp, C.POINTER(l)]),
     }

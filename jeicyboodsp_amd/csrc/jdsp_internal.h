@@ -143,6 +143,15 @@ int launch_mvdr(hipStream_t s, const short *left, const short *right, long n_blo
                 const MvdrState *st_in, MvdrState *st_out, const int *events, const DenoisePlan *plan,
                 const int *ver_base, const unsigned long long *snap_mask, double *delta, double *rver,
                 const double2 *steer, const float2 *table, short *out, float *precast);
+int launch_mvdr_shard_summary(hipStream_t s, const short *left_ext, const short *right_ext, long n_ext, long ext0,
+                              long b0, long b1, const MvdrState *zero_state, const int *events,
+                              const DenoisePlan *plan, const int *ver_base, const unsigned long long *snap_mask,
+                              const float2 *table, int *range, double *delta, double *total);
+int launch_mvdr_shard_finish(hipStream_t s, const short *left_ext, const short *right_ext, long n_ext, long ext0,
+                             long b0, long b1, const MvdrState *zero_state, MvdrState *scratch_state,
+                             const DenoisePlan *plan, const int *ver_base, const unsigned long long *snap_mask,
+                             const int *range, const double *delta, const double *sums_all, int rank, double *rver,
+                             const double2 *steer, const float2 *table, short *out, float *precast);
 // pitch_kernels.hip
 int launch_pitch(hipStream_t s, const short *pcm, long n_blocks, const short *prev_block, const float2 *table, int *arg,
                  float *rmax, float *autocorr);
@@ -210,4 +219,9 @@ struct jdsp_mvdr {
     int *events = nullptr, *ev_n = nullptr, *ver_base = nullptr;
     unsigned long long *snap_mask = nullptr;
     double *delta = nullptr, *rver = nullptr;
+    // sharded (multi-GPU) run in progress
+    long sh_ext0 = 0, sh_b0 = 0, sh_b1 = 0, sh_total = 0;
+    const int16_t *sh_left = nullptr, *sh_right = nullptr;
+    int *sh_range = nullptr;              // device: {first event, one past last, versions before the shard}
+    int *sh_zero_run = nullptr;
 };

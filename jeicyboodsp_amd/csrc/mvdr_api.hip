@@ -40,6 +40,9 @@ int jdsp_mvdr_create(jdsp_ctx *ctx, double d_time, jdsp_mvdr **out)
     if (e == hipSuccess) e = hipMalloc((void **)&h->plan, sizeof(jdsp::DenoisePlan));
     if (e == hipSuccess) e = hipMalloc((void **)&h->steer, sizeof(double2) * 1024);
     if (e == hipSuccess) e = hipMalloc((void **)&h->w_vad, sizeof(w));
+    if (e == hipSuccess) e = hipMalloc((void **)&h->sh_range, 4 * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc((void **)&h->sh_zero_run, sizeof(int));
+    if (e == hipSuccess) e = hipMemset(h->sh_zero_run, 0, sizeof(int));
     if (e == hipSuccess) e = hipMemcpy(h->steer, steer.data(), sizeof(double2) * 1024, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(h->w_vad, w, sizeof(w), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
@@ -66,6 +69,8 @@ int jdsp_mvdr_destroy(jdsp_mvdr *h)
     if (h->plan) (void)hipFree(h->plan);
     if (h->steer) (void)hipFree(h->steer);
     if (h->w_vad) (void)hipFree(h->w_vad);
+    if (h->sh_range) (void)hipFree(h->sh_range);
+    if (h->sh_zero_run) (void)hipFree(h->sh_zero_run);
     delete h;
     return JDSP_OK;
 }
@@ -172,6 +177,69 @@ int jdsp_mvdr_process(jdsp_mvdr *h, const int16_t *left_host, const int16_t *rig
     if (d_out) (void)hipFree(d_out);
     if (d_pre) (void)hipFree(d_pre);
     return rc;
+}
+
+/* ---- multi-GPU: one rank's share of one stereo stream ------------------------------------------ */
+int jdsp_mvdr_shard_vad_dev(jdsp_mvdr *h, const int16_t *left_ext_dev, const int16_t *right_ext_dev, long ext0, long b0,
+                            long b1, long n_total, uint8_t *flags_own_dev)
+{
+    if (!h) return JDSP_EINVAL;
+    jdsp_ctx *ctx = h->ctx;
+    if (!(0 <= ext0 && ext0 <= b0 && b0 <= b1 && b1 <= n_total) || (b0 >= 1 ? ext0 != b0 - 1 : ext0 != 0))
+        return fail(ctx, JDSP_EINVAL, "jdsp_mvdr_shard_vad: need ext0 = max(b0-1, 0) <= b0 <= b1 <= n_total");
+    if (b1 > b0 && (!left_ext_dev || !right_ext_dev || !flags_own_dev)) return fail(ctx, JDSP_EINVAL, "jdsp_mvdr_shard_vad: NULL buffer");
+    if (((uintptr_t)left_ext_dev & 15u) || ((uintptr_t)right_ext_dev & 15u))
+        return fail(ctx, JDSP_EINVAL, "jdsp_mvdr_shard_vad: inputs must be 16-byte aligned");
+    JDSP_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = mvdr_reserve(h, n_total);
+    if (!rc) rc = jdsp_mvdr_reset(h);
+    if (rc) return rc;
+    h->sh_ext0 = ext0; h->sh_b0 = b0; h->sh_b1 = b1; h->sh_total = n_total;
+    h->sh_left = left_ext_dev; h->sh_right = right_ext_dev;
+    if (jdsp::launch_vad(ctx->stream, left_ext_dev + (b0 - ext0) * 512, b1 - b0, h->w_vad, 0, flags_own_dev, nullptr, nullptr))
+        return fail(ctx, JDSP_EHIP, "vad launch", hipGetLastError());
+    return JDSP_OK;
+}
+
+int jdsp_mvdr_shard_summary_dev(jdsp_mvdr *h, const uint8_t *flags_all_dev, double *sum4_dev)
+{
+    if (!h) return JDSP_EINVAL;
+    jdsp_ctx *ctx = h->ctx;
+    if (!flags_all_dev || !sum4_dev) return fail(ctx, JDSP_EINVAL, "jdsp_mvdr_shard_summary: NULL buffer");
+    JDSP_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    if (jdsp::launch_run_plan(s, flags_all_dev, h->sh_total, h->sh_zero_run, nullptr, 0, h->ver_base, h->snap_mask, h->events,
+                              h->ev_n, h->plan) ||
+        jdsp::launch_mvdr_shard_summary(s, h->sh_left, h->sh_right, h->sh_b1 - h->sh_ext0, h->sh_ext0, h->sh_b0, h->sh_b1,
+                                        h->st[h->cur], h->events, h->plan, h->ver_base, h->snap_mask, ctx->stft1024_table,
+                                        h->sh_range, h->delta, sum4_dev))
+        return fail(ctx, JDSP_EHIP, "mvdr shard summary launch", hipGetLastError());
+    return JDSP_OK;
+}
+
+long jdsp_mvdr_shard_blocks_out(const jdsp_mvdr *h)
+{
+    if (!h) return 0;
+    const long lo = h->sh_b0 > 1 ? h->sh_b0 : 1;
+    return h->sh_b1 > lo ? h->sh_b1 - lo : 0;
+}
+
+int jdsp_mvdr_shard_finish_dev(jdsp_mvdr *h, const double *sums_all_dev, int world, int rank, int16_t *out_dev,
+                               float *precast_dev, long *n_out_blocks)
+{
+    if (!h) return JDSP_EINVAL;
+    jdsp_ctx *ctx = h->ctx;
+    const long n_out = jdsp_mvdr_shard_blocks_out(h);
+    if (n_out_blocks) *n_out_blocks = n_out;
+    if (!sums_all_dev || world < 1 || rank < 0 || rank >= world || (n_out > 0 && !out_dev))
+        return fail(ctx, JDSP_EINVAL, "jdsp_mvdr_shard_finish: bad argument");
+    JDSP_HIP(ctx, hipSetDevice(ctx->device));
+    if (jdsp::launch_mvdr_shard_finish(ctx->stream, h->sh_left, h->sh_right, h->sh_b1 - h->sh_ext0, h->sh_ext0, h->sh_b0,
+                                       h->sh_b1, h->st[h->cur], h->st[h->cur ^ 1], h->plan, h->ver_base, h->snap_mask,
+                                       h->sh_range, h->delta, sums_all_dev, rank, h->rver, h->steer, ctx->stft1024_table,
+                                       out_dev, precast_dev))
+        return fail(ctx, JDSP_EHIP, "mvdr shard finish launch", hipGetLastError());
+    return JDSP_OK;
 }
 
 int jdsp_mvdr_corr(jdsp_mvdr *h, double *corr4_host)

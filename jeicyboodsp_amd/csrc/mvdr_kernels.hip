@@ -49,18 +49,21 @@ __global__ __launch_bounds__(64) void mvdr_corr_kernel(const short *__restrict__
                                                        long n_blocks, const MvdrState *__restrict__ st_in,
                                                        const int *__restrict__ events,
                                                        const DenoisePlan *__restrict__ plan,
-                                                       const float2 *__restrict__ table, double *__restrict__ delta)
+                                                       const float2 *__restrict__ table, double *__restrict__ delta,
+                                                       const int *__restrict__ range, long ext0)
 {
+    // range (device, or NULL: every event) = {first, one past last} event this launch handles;
+    // ext0 = global index of the first block the pcm pointers hold (sharded runs)
     __shared__ __attribute__((aligned(16))) float2 lds[kWaveLdsComplex];
     __shared__ __attribute__((aligned(16))) unsigned int stage[256];
     const int lane = threadIdx.x;
-    const int n_events = plan->n_events;
-    if ((int)blockIdx.x >= n_events) return;
+    const int e_lo = range ? range[0] : 0, e_hi = range ? range[1] : plan->n_events;
+    if (e_lo + (int)blockIdx.x >= e_hi) return;
     WaveTwiddles tw;
     load_wave_twiddles(tw, table, lane);
     const float2 wsp[2] = {table[kStftSplit + 2 * lane], table[kStftSplit + 2 * lane + 1]};
-    for (int e = blockIdx.x; e < n_events; e += gridDim.x) {
-        const long j = events[e];
+    for (int e = e_lo + blockIdx.x; e < e_hi; e += gridDim.x) {
+        const long j = events[e] - ext0;
         float2 llo[8], lhi[8], rlo[8], rhi[8], v[8];
         unsigned int raw[8];
         relayout_half(stage, lane, mvdr_load_block(left, n_blocks, st_in->prev_l, j - 1, lane), raw);
@@ -91,26 +94,34 @@ __global__ __launch_bounds__(64) void mvdr_corr_kernel(const short *__restrict__
             s10 += __shfl_xor(s10, o); s11 += __shfl_xor(s11, o);
         }
         if (lane == 0) {
-            double *d = delta + (size_t)e * 4;
+            double *d = delta + (size_t)(e - e_lo) * 4;
             d[0] = s00 / 1024.0; d[1] = s01 / 1024.0; d[2] = s10 / 1024.0; d[3] = s11 / 1024.0;
         }
     }
 }
 
-// R after event e: rver[e+1] = rver[e] + delta[e]; rver[0] = the matrix carried in.
+// R after event e: rver[e+1] = rver[e] + delta[e]; rver[0] = the matrix carried in (the state's,
+// or for a sharded run the sum of the earlier ranks' totals).  total (may be NULL) = sum of delta.
 __global__ void mvdr_prefix_kernel(const double *__restrict__ delta, const DenoisePlan *__restrict__ plan,
-                                   const MvdrState *__restrict__ st_in, MvdrState *st_out, double *__restrict__ rver)
+                                   const int *__restrict__ range, const double *__restrict__ r_in,
+                                   const double *__restrict__ sums_all, int rank, MvdrState *st_out,
+                                   double *__restrict__ rver, double *__restrict__ total)
 {
     const int c = threadIdx.x;
     if (c >= 4) return;
-    double acc = st_in->corr[c];
-    rver[c] = acc;
-    const int n = plan->n_events;
+    double acc = r_in ? r_in[c] : 0.0;
+    if (sums_all)
+        for (int q = 0; q < rank; q++) acc += sums_all[q * 4 + c];
+    if (rver) rver[c] = acc;
+    const int n = range ? range[1] - range[0] : plan->n_events;
+    double sum = 0.0;
     for (int e = 0; e < n; e++) {
         acc += delta[(size_t)e * 4 + c];
-        rver[(size_t)(e + 1) * 4 + c] = acc;
+        sum += delta[(size_t)e * 4 + c];
+        if (rver) rver[(size_t)(e + 1) * 4 + c] = acc;
     }
-    st_out->corr[c] = acc;
+    if (st_out) st_out->corr[c] = acc;
+    if (total) total[c] = sum;
 }
 
 // frame position p of block j: [first 511 samples of block j-1, block j, 0]  (:136-141,:195-196)
@@ -130,7 +141,7 @@ __global__ __launch_bounds__(64) void mvdr_kernel(const short *__restrict__ left
                                                   const unsigned long long *__restrict__ snap_mask,
                                                   const double *__restrict__ rver, const double2 *__restrict__ steer,
                                                   const float2 *__restrict__ table, short *__restrict__ out,
-                                                  float *__restrict__ precast)
+                                                  float *__restrict__ precast, DenoiseShard sh)
 {
     __shared__ __attribute__((aligned(16))) float2 lds[kWaveLdsComplex];
     __shared__ __attribute__((aligned(16))) float2 merged[1024];
@@ -160,7 +171,10 @@ __global__ __launch_bounds__(64) void mvdr_kernel(const short *__restrict__ left
     spectrum_of(v, lds, lane, tw, wsp, rlo, rhi);
 
     // mxAutoCorr.inverse() (:170) for the matrix in effect at this block
-    const double *R = rver + (size_t)version_of(ver_base, snap_mask, j) * 4;
+    int ver = version_of(ver_base, snap_mask, j + sh.ver_block_off);
+    if (sh.ver_row_off) ver -= *sh.ver_row_off;
+    if (ver < 0) ver = 0;
+    const double *R = rver + (size_t)ver * 4;
     const double a = R[0], b = R[1], c = R[2], d = R[3];
     const double invdet = 1.0 / (a * d - b * c);
     const double i00 = d * invdet, i01 = -b * invdet, i10 = -c * invdet, i11 = a * invdet;
@@ -214,8 +228,8 @@ __global__ __launch_bounds__(64) void mvdr_kernel(const short *__restrict__ left
     wave_lds_fence();
     wave_fft512<true>(y, lds, lane, tw);
 
-    const long first_emit = calls_before >= 1 ? 0 : 1;              // :201-204: the first call's block is dropped
-    if (j >= first_emit) {
+    const long first_emit = sh.emit_from;                           // :201-204: the first call's block is dropped
+    if (j >= first_emit && j < sh.emit_to) {
         short *o = out + (j - first_emit) * 512;
         float *pc = precast ? precast + (j - first_emit) * 512 : nullptr;
 #pragma unroll
@@ -240,11 +254,70 @@ int launch_mvdr(hipStream_t s, const short *left, const short *right, long n_blo
     if (n_blocks <= 0) return 0;
     const long g1 = n_blocks < 2048 ? n_blocks : 2048;
     hipLaunchKernelGGL(mvdr_corr_kernel, dim3((unsigned)g1), dim3(64), 0, s, left, right, n_blocks, st_in, events, plan,
-                       table, delta);
-    hipLaunchKernelGGL(mvdr_prefix_kernel, dim3(1), dim3(64), 0, s, delta, plan, st_in, st_out, rver);
+                       table, delta, (const int *)nullptr, 0L);
+    hipLaunchKernelGGL(mvdr_prefix_kernel, dim3(1), dim3(64), 0, s, delta, plan, (const int *)nullptr, st_in->corr,
+                       (const double *)nullptr, 0, st_out, rver, (double *)nullptr);
+    DenoiseShard sh;
+    sh.ver_block_off = 0;
+    sh.ver_row_off = nullptr;
+    sh.emit_from = calls_before >= 1 ? 0 : 1;
+    sh.emit_to = n_blocks;
     const long grid = (n_blocks + 7) / 8 * 8;
     hipLaunchKernelGGL(mvdr_kernel, dim3((unsigned)grid), dim3(64), 0, s, left, right, n_blocks, calls_before, st_in,
-                       st_out, ver_base, snap_mask, rver, steer, table, out, precast);
+                       st_out, ver_base, snap_mask, rver, steer, table, out, precast, sh);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// ---- sharded run (multi-GPU): see include/jdsp.h "sharded MVDR" --------------------------------
+__global__ void mvdr_event_range_kernel(const int *__restrict__ events, const DenoisePlan *__restrict__ plan,
+                                        const int *__restrict__ ver_base,
+                                        const unsigned long long *__restrict__ snap_mask, long b0, long b1,
+                                        int *__restrict__ range)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int n = plan->n_events;
+    int lo = 0, hi = n;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (events[mid] < b0) lo = mid + 1; else hi = mid; }
+    range[0] = lo;
+    hi = n;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (events[mid] < b1) lo = mid + 1; else hi = mid; }
+    range[1] = lo;
+    range[2] = b0 > 0 ? version_of(ver_base, snap_mask, b0 - 1) : 0;
+}
+
+int launch_mvdr_shard_summary(hipStream_t s, const short *left_ext, const short *right_ext, long n_ext, long ext0,
+                              long b0, long b1, const MvdrState *zero_state, const int *events,
+                              const DenoisePlan *plan, const int *ver_base, const unsigned long long *snap_mask,
+                              const float2 *table, int *range, double *delta, double *total)
+{
+    hipLaunchKernelGGL(mvdr_event_range_kernel, dim3(1), dim3(64), 0, s, events, plan, ver_base, snap_mask, b0, b1, range);
+    const long own = b1 - b0;
+    const long g1 = own < 2048 ? (own > 0 ? own : 1) : 2048;
+    hipLaunchKernelGGL(mvdr_corr_kernel, dim3((unsigned)g1), dim3(64), 0, s, left_ext, right_ext, n_ext, zero_state, events,
+                       plan, table, delta, (const int *)range, ext0);
+    hipLaunchKernelGGL(mvdr_prefix_kernel, dim3(1), dim3(64), 0, s, delta, plan, (const int *)range,
+                       (const double *)nullptr, (const double *)nullptr, 0, (MvdrState *)nullptr, (double *)nullptr, total);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+int launch_mvdr_shard_finish(hipStream_t s, const short *left_ext, const short *right_ext, long n_ext, long ext0,
+                             long b0, long b1, const MvdrState *zero_state, MvdrState *scratch_state,
+                             const DenoisePlan *plan, const int *ver_base, const unsigned long long *snap_mask,
+                             const int *range, const double *delta, const double *sums_all, int rank, double *rver,
+                             const double2 *steer, const float2 *table, short *out, float *precast)
+{
+    hipLaunchKernelGGL(mvdr_prefix_kernel, dim3(1), dim3(64), 0, s, delta, plan, range, (const double *)nullptr, sums_all,
+                       rank, (MvdrState *)nullptr, rver, (double *)nullptr);
+    DenoiseShard sh;
+    sh.ver_block_off = ext0;
+    sh.ver_row_off = range + 2;
+    const long lo = b0 > 1 ? b0 : 1;                                  // :201-204: global block 0 emits nothing
+    sh.emit_from = lo - ext0;
+    sh.emit_to = b1 - ext0;
+    if (sh.emit_to <= sh.emit_from) return 0;
+    const long grid = (n_ext + 7) / 8 * 8;
+    hipLaunchKernelGGL(mvdr_kernel, dim3((unsigned)grid), dim3(64), 0, s, left_ext, right_ext, n_ext, ext0, zero_state,
+                       scratch_state, ver_base, snap_mask, rver, steer, table, out, precast, sh);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

@@ -437,6 +437,31 @@ class Mvdr:
         self.eng._ck(L.jdsp_mvdr_corr(self._h, c.ctypes.data_as(C.c_void_p)))
         return c
 
+    # ---- one rank's share of a global stream (jdsp_mvdr_shard_*)
+    def shard_vad(self, left_ext, right_ext, ext0, b0, b1, n_total):
+        import torch
+        flags = torch.empty(max(b1 - b0, 1), dtype=torch.uint8, device=left_ext.device)
+        self.eng._use_torch_stream()
+        self.eng._ck(L.jdsp_mvdr_shard_vad_dev(self._h, C.c_void_p(left_ext.data_ptr()), C.c_void_p(right_ext.data_ptr()),
+                                               ext0, b0, b1, n_total, C.c_void_p(flags.data_ptr())))
+        return flags[: b1 - b0]
+
+    def shard_summary(self, flags_all):
+        import torch
+        out = torch.empty(4, dtype=torch.float64, device=flags_all.device)
+        self.eng._use_torch_stream()
+        self.eng._ck(L.jdsp_mvdr_shard_summary_dev(self._h, C.c_void_p(flags_all.data_ptr()), C.c_void_p(out.data_ptr())))
+        return out
+
+    def shard_finish(self, sums_all, world, rank):
+        import torch
+        n_out = L.jdsp_mvdr_shard_blocks_out(self._h)
+        out = torch.empty(max(n_out, 1) * 512, dtype=torch.int16, device=sums_all.device)
+        self.eng._use_torch_stream()
+        self.eng._ck(L.jdsp_mvdr_shard_finish_dev(self._h, C.c_void_p(sums_all.data_ptr()), world, rank,
+                                                  C.c_void_p(out.data_ptr()), None, None))
+        return out[: n_out * 512]
+
     def process(self, left, right, want_precast=False):
         if _is_torch(left):
             import torch

@@ -96,3 +96,29 @@ def test_mvdr_device_path(eng, oracle):
     torch.cuda.synchronize()
     check(out.cpu().numpy(), pre.cpu().numpy(), o_out, o_pre)
     m.close()
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+def test_mvdr_sharded_equals_single(eng, oracle, world):
+    """Multi-GPU path on one GPU: simulated ranks, all-gathers = concatenations."""
+    import torch
+    from jeicyboodsp_amd import sharding
+    nb = 150
+    L, R = stereo(9, nb, quiet=((0, 8), (20, 5), (40, 12), (70, 30), (120, 9)))
+    o_out, _, _, _ = oracle.mvdr_stream(L, R, 1e-4)
+    tl, tr = torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()
+    ranks = []
+    for r in range(world):
+        b0, cnt = sharding.split_even(nb, r, world)
+        ext0 = max(b0 - 1, 0)
+        ranks.append(dict(m=eng.mvdr(1e-4), ext0=ext0, b0=b0, b1=b0 + cnt,
+                          l=tl[ext0 * 512:(b0 + cnt) * 512].clone(), r=tr[ext0 * 512:(b0 + cnt) * 512].clone()))
+    flags = torch.cat([k["m"].shard_vad(k["l"], k["r"], k["ext0"], k["b0"], k["b1"], nb) for k in ranks]).contiguous()
+    sums = torch.stack([k["m"].shard_summary(flags) for k in ranks]).contiguous()
+    outs = [k["m"].shard_finish(sums, world, r) for r, k in enumerate(ranks)]
+    torch.cuda.synchronize()
+    got = torch.cat(outs).cpu().numpy()
+    for k in ranks:
+        k["m"].close()
+    assert got.shape == o_out.shape
+    assert np.abs(got.astype(np.int32) - o_out.astype(np.int32)).max() <= 1
