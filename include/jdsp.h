@@ -241,6 +241,25 @@ long jdsp_mvdr_shard_blocks_out(const jdsp_mvdr *h);
 int jdsp_mvdr_shard_finish_dev(jdsp_mvdr *h, const double *sums_all_dev, int world, int rank, int16_t *out_dev,
                                float *precast_dev, long *n_out_blocks);
 
+/* ---- MVDR generalised to n microphones, per-bin covariance (BASELINE config 5) ------------- */
+/* NOT a reference function: the reference has 2 microphones and one real 2x2 matrix for all
+ * bins (jdsp_mvdr above is that algorithm).  This keeps its framing, VAD, run counter and weight
+ * formula and makes the correlation a Hermitian n_mics x n_mics matrix PER BIN, accumulated over
+ * the same noise frames, R_k += X_k X_k^H / 1024; w_k = R_k^-1 c_k / (c_k^H R_k^-1 c_k) with
+ * c_k[m] = exp(j 2 PI f_k delays_s[m]); y = IDFT(w^H X).  loading >= 0 adds
+ * loading * trace(R_k)/n_mics to the diagonal (with 0, R_k is singular until n_mics noise frames
+ * have been seen, and the output is NaN -> 0 like the reference's before its first estimate).
+ * pcm: n_mics planes, chan_stride samples apart, each n_blocks*512 samples. 2 <= n_mics <= 8. */
+typedef struct jdsp_mvdrn jdsp_mvdrn;
+int jdsp_mvdrn_create(jdsp_ctx *ctx, int n_mics, const double *delays_s, double loading, jdsp_mvdrn **out);
+int jdsp_mvdrn_destroy(jdsp_mvdrn *h);
+int jdsp_mvdrn_reset(jdsp_mvdrn *h);
+long jdsp_mvdrn_blocks_out(const jdsp_mvdrn *h, long n_blocks);
+int jdsp_mvdrn_process_dev(jdsp_mvdrn *h, const int16_t *pcm_dev, long chan_stride, long n_blocks, int16_t *out_dev,
+                           float *precast_dev, long *n_out_blocks);
+int jdsp_mvdrn_process(jdsp_mvdrn *h, const int16_t *pcm_host, long chan_stride, long n_blocks, int16_t *out_host,
+                       float *precast_host, long *n_out_blocks);
+
 /* ---- MFCC ---------------------------------------------------------------------- */
 /* MFCCFeatureExtraction_auto_version1.cpp.  The #defines at :23-33 become a runtime
  * configuration; jdsp_mfcc_native_cfg() fills in the reference's values

@@ -101,6 +101,12 @@ def _load():
         "jdsp_mvdr_shard_summary_dev": (i, [vp, vp, vp]),
         "jdsp_mvdr_shard_blocks_out": (l, [vp]),
         "jdsp_mvdr_shard_finish_dev": (i, [vp, vp, i, i, vp, vp, C.POINTER(l)]),
+        "jdsp_mvdrn_create": (i, [vp, i, vp, C.c_double, C.POINTER(vp)]),
+        "jdsp_mvdrn_destroy": (i, [vp]),
+        "jdsp_mvdrn_reset": (i, [vp]),
+        "jdsp_mvdrn_blocks_out": (l, [vp, l]),
+        "jdsp_mvdrn_process_dev": (i, [vp, vp, l, l, vp, vp, C.POINTER(l)]),
+        "jdsp_mvdrn_process": (i, [vp, vp, l, l, vp, vp, C.POINTER(l)]),
         "jdsp_stft_i16_dev": (i, [vp, vp, l, i, i, vp]),
         "jdsp_stft_i16": (i, [vp, vp, l, i, i, vp, C.POINTER(l)]),
     }

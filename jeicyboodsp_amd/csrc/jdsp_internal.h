@@ -152,6 +152,11 @@ int launch_mvdr_shard_finish(hipStream_t s, const short *left_ext, const short *
                              const DenoisePlan *plan, const int *ver_base, const unsigned long long *snap_mask,
                              const int *range, const double *delta, const double *sums_all, int rank, double *rver,
                              const double2 *steer, const float2 *table, short *out, float *precast);
+// mvdrn_kernels.hip
+int launch_mvdrn(hipStream_t s, const short *pcm, long chan_stride, int n_mics, long n_blocks, long calls_before,
+                 const short *prev_in, short *prev_out, const int *events, const DenoisePlan *plan, const int *ver_base,
+                 const unsigned long long *snap_mask, float2 *spec, const double2 *cov_in, double2 *cov_out,
+                 const double2 *steer, double loading, float2 *weights, const float2 *table, short *out, float *precast);
 // pitch_kernels.hip
 int launch_pitch(hipStream_t s, const short *pcm, long n_blocks, const short *prev_block, const float2 *table, int *arg,
                  float *rmax, float *autocorr);
@@ -224,4 +229,23 @@ struct jdsp_mvdr {
     const int16_t *sh_left = nullptr, *sh_right = nullptr;
     int *sh_range = nullptr;              // device: {first event, one past last, versions before the shard}
     int *sh_zero_run = nullptr;
+};
+
+struct jdsp_mvdrn {
+    jdsp_ctx *ctx = nullptr;
+    int n_mics = 0;
+    double loading = 0;
+    long calls = 0;
+    int cur = 0;
+    double2 *cov[2] = {nullptr, nullptr};     // [513][64] per-bin covariance, ping-pong
+    short *prev[2] = {nullptr, nullptr};      // [8][512] previous block per microphone
+    int *run_len[2] = {nullptr, nullptr};
+    jdsp::DenoisePlan *plan = nullptr;
+    double2 *steer = nullptr;                 // [513][8]
+    double *w_vad = nullptr;
+    long cap_blocks = 0;
+    unsigned char *flags = nullptr;
+    int *events = nullptr, *ev_n = nullptr, *ver_base = nullptr;
+    unsigned long long *snap_mask = nullptr;
+    float2 *spec = nullptr, *weights = nullptr;
 };

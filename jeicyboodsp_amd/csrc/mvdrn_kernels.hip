@@ -1,0 +1,253 @@
+// mvdrn_kernels.hip -- the MVDR beamformer generalised to n_mics <= 8 microphones with a per-bin
+// covariance (BASELINE config 5 / SURVEY §8f rank 3).  The reference (BeamForming_MVDR_ver1.cpp)
+// has 2 microphones and ONE real 2x2 matrix for all bins -- that exact algorithm is
+// mvdr_kernels.hip; this file keeps its framing, VAD, run counter and weight formula
+// (w = R^-1 c / (c^H R^-1 c), :170-171) and makes R a Hermitian n_mics x n_mics matrix per bin.
+// No MFMA: 8x8 systems, one per bin, solved by Gauss-Jordan across the 64 lanes of a wave in FP64.
+//
+//   vad_kernel / plan_kernel (denoise_kernels.hip)   as for the 2-microphone path
+//   mvdrn_event_spectra_kernel    X_m[k], k = 0..512, of every estimation frame and microphone
+//   mvdrn_update_kernel           one wave per bin: R_k += X X^H / 1024 per event, weights after each
+//   mvdrn_apply_kernel            one wave per block: n_mics transforms, y = IDFT(w^H X)
+#include "frame_io.h"
+#include "jdsp_internal.h"
+
+namespace jdsp {
+
+constexpr int kMvnBins = 513;
+
+__device__ __forceinline__ u32x4 mvn_block(const short *__restrict__ chan, long n_blocks, const short *__restrict__ prev,
+                                           long j, int lane)
+{
+    u32x4 zero = {0u, 0u, 0u, 0u};
+    if (j >= 0 && j < n_blocks) return reinterpret_cast<const u32x4 *>(chan + j * 512)[lane];
+    if (j == -1 && prev) return reinterpret_cast<const u32x4 *>(prev)[lane];
+    return zero;
+}
+
+__device__ __forceinline__ void mvn_spectrum(float2 (&v)[8], float2 *lds, int lane, const WaveTwiddles &tw,
+                                             const float2 *wsp, float2 (&lo)[8], float2 (&hi)[8])
+{
+    wave_fft512<false>(v, lds, lane, tw);
+#pragma unroll
+    for (int d = 0; d < 8; d++) lds[lane + 64 * d] = v[d];
+    wave_lds_fence();
+#define JDSP_SPLIT(J)                                                                          \
+    {                                                                                          \
+        const int m = 128 * J + 2 * lane;                                                      \
+        const float4 zz = *reinterpret_cast<const float4 *>(&lds[m]);                          \
+        const float2 zr0 = lds[(512 - m) & 511], zr1 = lds[511 - m];                           \
+        split_fwd<J>(make_float2(zz.x, zz.y), zr0, wsp[0], lo[2 * J], hi[2 * J]);             \
+        split_fwd<J>(make_float2(zz.z, zz.w), zr1, wsp[1], lo[2 * J + 1], hi[2 * J + 1]);     \
+    }
+    JDSP_SPLIT(0) JDSP_SPLIT(1) JDSP_SPLIT(2) JDSP_SPLIT(3)
+#undef JDSP_SPLIT
+    wave_lds_fence();
+}
+
+// spec[(e * n_mics + m) * 513 + k] = X_m[k] of the frame [block j-1, block j], j = events[e]
+__global__ __launch_bounds__(64) void mvdrn_event_spectra_kernel(const short *__restrict__ pcm, long chan_stride,
+                                                                 int n_mics, long n_blocks,
+                                                                 const short *__restrict__ prev_all,
+                                                                 const int *__restrict__ events,
+                                                                 const DenoisePlan *__restrict__ plan,
+                                                                 const float2 *__restrict__ table,
+                                                                 float2 *__restrict__ spec)
+{
+    __shared__ __attribute__((aligned(16))) float2 lds[kWaveLdsComplex];
+    __shared__ __attribute__((aligned(16))) unsigned int stage[256];
+    const int lane = threadIdx.x;
+    const long total = (long)plan->n_events * n_mics;
+    if ((long)blockIdx.x >= total) return;
+    WaveTwiddles tw;
+    load_wave_twiddles(tw, table, lane);
+    const float2 wsp[2] = {table[kStftSplit + 2 * lane], table[kStftSplit + 2 * lane + 1]};
+    for (long w = blockIdx.x; w < total; w += gridDim.x) {
+        const int e = (int)(w / n_mics), m = (int)(w % n_mics);
+        const long j = events[e];
+        const short *chan = pcm + (size_t)m * chan_stride;
+        const short *prev = prev_all + (size_t)m * 512;
+        unsigned int raw[8];
+        relayout_half(stage, lane, mvn_block(chan, n_blocks, prev, j - 1, lane), raw);
+        relayout_half(stage, lane, mvn_block(chan, n_blocks, prev, j, lane), raw + 4);
+        float2 v[8], lo[8], hi[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) { const float2 s = unpack_i16x2(raw[r]); v[r] = make_float2(0.5f * s.x, 0.5f * s.y); }
+        mvn_spectrum(v, lds, lane, tw, wsp, lo, hi);
+        float2 *dst = spec + (size_t)w * kMvnBins;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            dst[128 * q + 2 * lane] = lo[2 * q];
+            dst[128 * q + 2 * lane + 1] = lo[2 * q + 1];
+        }
+        if (lane == 0) dst[512] = hi[0];
+    }
+}
+
+// ---- complex FP64 helpers on (re, im) pairs
+struct cd { double x, y; };
+__device__ __forceinline__ cd cd_mul(cd a, cd b) { return {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
+__device__ __forceinline__ cd cd_sub(cd a, cd b) { return {a.x - b.x, a.y - b.y}; }
+__device__ __forceinline__ cd cd_inv(cd a) { const double d = a.x * a.x + a.y * a.y; return {a.x / d, -a.y / d}; }
+__device__ __forceinline__ cd cd_shfl(cd a, int src) { return {__shfl(a.x, src), __shfl(a.y, src)}; }
+
+// One wave owns bin k; lane (r, c) = (lane >> 3, lane & 7) owns R_k[r][c].  After every event
+// the weights are recomputed: Gauss-Jordan on [R' | c] across the lanes (R' Hermitian positive
+// definite once loaded, so no pivoting), then w = x / (c^H x).  Version 0 = the matrix carried in.
+__global__ __launch_bounds__(64) void mvdrn_update_kernel(const float2 *__restrict__ spec, int n_mics,
+                                                          const DenoisePlan *__restrict__ plan,
+                                                          const double2 *__restrict__ cov_in, double2 *__restrict__ cov_out,
+                                                          const double2 *__restrict__ steer, double loading,
+                                                          float2 *__restrict__ weights)
+{
+    const int k = blockIdx.x, lane = threadIdx.x;
+    const int r = lane >> 3, c = lane & 7;
+    const bool live = r < n_mics && c < n_mics;
+    const double2 rin = cov_in[(size_t)k * 64 + lane];
+    cd R = {live ? rin.x : 0.0, live ? rin.y : 0.0};
+    const double2 sr = steer[(size_t)k * 8 + r];
+    const cd cr = {r < n_mics ? sr.x : 0.0, r < n_mics ? sr.y : 0.0};
+    const int n_events = plan->n_events;
+    for (int v = 0; v <= n_events; v++) {
+        if (v > 0) {
+            const float2 *ev = spec + (size_t)(v - 1) * n_mics * kMvnBins + k;
+            const float2 xr = live ? ev[(size_t)r * kMvnBins] : make_float2(0.f, 0.f);
+            const float2 xc = live ? ev[(size_t)c * kMvnBins] : make_float2(0.f, 0.f);
+            // R[r][c] += X_r conj(X_c) / 1024
+            R.x += ((double)xr.x * xc.x + (double)xr.y * xc.y) * (1.0 / 1024.0);
+            R.y += ((double)xr.y * xc.x - (double)xr.x * xc.y) * (1.0 / 1024.0);
+        }
+        double tr = 0.0;
+        for (int d = 0; d < n_mics; d++) tr += __shfl(R.x, 9 * d);
+        cd A = R;
+        if (live && r == c) A.x += loading * tr / n_mics;
+        if (!live) A = {r == c ? 1.0 : 0.0, 0.0};
+        cd b = cr;
+        for (int p = 0; p < n_mics; p++) {
+            const cd inv = cd_inv(cd_shfl(A, 9 * p));
+            const cd rowp = cd_mul(cd_shfl(A, 8 * p + c), inv);
+            const cd bp = cd_mul(cd_shfl(b, 8 * p), inv);
+            const cd f = cd_shfl(A, 8 * r + p);
+            if (r == p) { A = rowp; b = bp; }
+            else { A = cd_sub(A, cd_mul(f, rowp)); b = cd_sub(b, cd_mul(f, bp)); }
+        }
+        cd den = {0.0, 0.0};                                   // c^H x
+        for (int d = 0; d < n_mics; d++) {
+            const cd xd = cd_shfl(b, 8 * d);
+            const cd cdv = cd_shfl(cr, 8 * d);
+            den.x += cdv.x * xd.x + cdv.y * xd.y;
+            den.y += cdv.x * xd.y - cdv.y * xd.x;
+        }
+        const cd w = cd_mul(b, cd_inv(den));
+        if (c == 0 && r < n_mics) weights[((size_t)v * kMvnBins + k) * 8 + r] = make_float2((float)w.x, (float)w.y);
+    }
+    cov_out[(size_t)k * 64 + lane] = make_double2(R.x, R.y);
+}
+
+// frame position p of block j for one channel: [first 511 samples of block j-1, block j, 0]
+__device__ __forceinline__ float mvn_sample(const short *__restrict__ chan, const short *__restrict__ prev, long j,
+                                            bool have_prev, int p)
+{
+    if (p >= 1023) return 0.f;
+    if (p >= 511) return (float)chan[j * 512 + (p - 511)];
+    if (!have_prev) return 0.f;
+    return j > 0 ? (float)chan[(j - 1) * 512 + p] : (float)prev[p];
+}
+
+__global__ __launch_bounds__(64) void mvdrn_apply_kernel(const short *__restrict__ pcm, long chan_stride, int n_mics,
+                                                         long n_blocks, long calls_before,
+                                                         const short *__restrict__ prev_in, short *__restrict__ prev_out,
+                                                         const int *__restrict__ ver_base,
+                                                         const unsigned long long *__restrict__ snap_mask,
+                                                         const float2 *__restrict__ weights,
+                                                         const float2 *__restrict__ table, short *__restrict__ out,
+                                                         float *__restrict__ precast)
+{
+    __shared__ __attribute__((aligned(16))) float2 lds[kWaveLdsComplex];
+    const int lane = threadIdx.x;
+    const long per_xcd = (gridDim.x + 7) >> 3;
+    const long j = (long)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (j >= n_blocks) return;
+    WaveTwiddles tw;
+    load_wave_twiddles(tw, table, lane);
+    const float2 wsp[2] = {table[kStftSplit + 2 * lane], table[kStftSplit + 2 * lane + 1]};
+    const bool have_prev = calls_before + j > 0;
+    const float2 *W = weights + (size_t)version_of(ver_base, snap_mask, j) * kMvnBins * 8;
+
+    float2 ylo[8], yhi[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) { ylo[q] = make_float2(0.f, 0.f); yhi[q] = make_float2(0.f, 0.f); }
+    for (int m = 0; m < n_mics; m++) {
+        const short *chan = pcm + (size_t)m * chan_stride;
+        const short *prev = prev_in + (size_t)m * 512;
+        float2 v[8], lo[8], hi[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const int p = 2 * lane + 128 * r;
+            v[r] = make_float2(0.5f * mvn_sample(chan, prev, j, have_prev, p), 0.5f * mvn_sample(chan, prev, j, have_prev, p + 1));
+        }
+        mvn_spectrum(v, lds, lane, tw, wsp, lo, hi);
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const int bin = 128 * (q >> 1) + 2 * lane + (q & 1);            // 0..511; its partner is bin + 512
+            // Y[k] = sum_m conj(w_k[m]) X_m[k];  for k > 512, w_k = conj(w_{1024-k})
+            const float2 wl = W[(size_t)bin * 8 + m];
+            ylo[q].x += wl.x * lo[q].x + wl.y * lo[q].y;
+            ylo[q].y += wl.x * lo[q].y - wl.y * lo[q].x;
+            const float2 wh = W[(size_t)(512 - bin) * 8 + m];               // bin + 512 mirrors to 512 - bin
+            if (bin == 0) {                                                 // k = 512 itself: not mirrored
+                yhi[q].x += wh.x * hi[q].x + wh.y * hi[q].y;
+                yhi[q].y += wh.x * hi[q].y - wh.y * hi[q].x;
+            } else {
+                yhi[q] = cadd(yhi[q], cmul(wh, hi[q]));
+            }
+        }
+        if (j == n_blocks - 1)
+            reinterpret_cast<u32x4 *>(prev_out + (size_t)m * 512)[lane] = reinterpret_cast<const u32x4 *>(chan + j * 512)[lane];
+    }
+    float2 z[8];
+    z[0] = presplit_inv<0>(ylo[0], yhi[0], wsp[0]); z[1] = presplit_inv<0>(ylo[1], yhi[1], wsp[1]);
+    z[2] = presplit_inv<1>(ylo[2], yhi[2], wsp[0]); z[3] = presplit_inv<1>(ylo[3], yhi[3], wsp[1]);
+    z[4] = presplit_inv<2>(ylo[4], yhi[4], wsp[0]); z[5] = presplit_inv<2>(ylo[5], yhi[5], wsp[1]);
+    z[6] = presplit_inv<3>(ylo[6], yhi[6], wsp[0]); z[7] = presplit_inv<3>(ylo[7], yhi[7], wsp[1]);
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+        *reinterpret_cast<float4 *>(&lds[128 * q + 2 * lane]) = make_float4(z[2 * q].x, z[2 * q].y, z[2 * q + 1].x, z[2 * q + 1].y);
+    wave_lds_fence();
+    float2 y[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) y[r] = lds[lane + 64 * r];
+    wave_lds_fence();
+    wave_fft512<true>(y, lds, lane, tw);
+    const long first_emit = calls_before >= 1 ? 0 : 1;
+    if (j >= first_emit) {
+        short *o = out + (j - first_emit) * 512;
+        float *pc = precast ? precast + (j - first_emit) * 512 : nullptr;
+#pragma unroll
+        for (int dd = 0; dd < 8; dd++) {
+            const int i0 = 2 * lane + 128 * dd - 511;
+            const float s0 = y[dd].x * (1.0f / 1024.0f), s1 = y[dd].y * (1.0f / 1024.0f);
+            if (i0 >= 0 && i0 < 512) { o[i0] = (short)cast_i16_bits(s0); if (pc) pc[i0] = s0; }
+            if (i0 + 1 >= 0 && i0 + 1 < 512) { o[i0 + 1] = (short)cast_i16_bits(s1); if (pc) pc[i0 + 1] = s1; }
+        }
+    }
+}
+
+int launch_mvdrn(hipStream_t s, const short *pcm, long chan_stride, int n_mics, long n_blocks, long calls_before,
+                 const short *prev_in, short *prev_out, const int *events, const DenoisePlan *plan, const int *ver_base,
+                 const unsigned long long *snap_mask, float2 *spec, const double2 *cov_in, double2 *cov_out,
+                 const double2 *steer, double loading, float2 *weights, const float2 *table, short *out, float *precast)
+{
+    if (n_blocks <= 0) return 0;
+    const long g1 = n_blocks * n_mics < 4096 ? n_blocks * n_mics : 4096;
+    hipLaunchKernelGGL(mvdrn_event_spectra_kernel, dim3((unsigned)g1), dim3(64), 0, s, pcm, chan_stride, n_mics, n_blocks,
+                       prev_in, events, plan, table, spec);
+    hipLaunchKernelGGL(mvdrn_update_kernel, dim3(kMvnBins), dim3(64), 0, s, spec, n_mics, plan, cov_in, cov_out, steer,
+                       loading, weights);
+    const long grid = (n_blocks + 7) / 8 * 8;
+    hipLaunchKernelGGL(mvdrn_apply_kernel, dim3((unsigned)grid), dim3(64), 0, s, pcm, chan_stride, n_mics, n_blocks,
+                       calls_before, prev_in, prev_out, ver_base, snap_mask, weights, table, out, precast);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+}  // namespace jdsp

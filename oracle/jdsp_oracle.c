@@ -621,3 +621,104 @@ long orc_mvdr_stream(const short *left, const short *right, long n_blocks, doubl
     free(fl); free(FL); free(fr); free(FR); free(mg); free(MG);
     return n_out;
 }
+
+/* ------------------------------------------------------------------------- */
+/* Generalised MVDR (see jdsp_oracle.h): no reference counterpart. */
+#define MVN_MAX 8
+static int solve_cplx(int n, double complex A[MVN_MAX][MVN_MAX], double complex *b)
+{
+    for (int p = 0; p < n; p++) {
+        int best = p;
+        for (int r = p + 1; r < n; r++)
+            if (cabs(A[r][p]) > cabs(A[best][p])) best = r;
+        if (best != p) {
+            for (int c = 0; c < n; c++) { double complex t = A[p][c]; A[p][c] = A[best][c]; A[best][c] = t; }
+            double complex t = b[p]; b[p] = b[best]; b[best] = t;
+        }
+        double complex piv = A[p][p];
+        for (int c = 0; c < n; c++) A[p][c] /= piv;
+        b[p] /= piv;
+        for (int r = 0; r < n; r++) {
+            if (r == p) continue;
+            double complex f = A[r][p];
+            for (int c = 0; c < n; c++) A[r][c] -= f * A[p][c];
+            b[r] -= f * b[p];
+        }
+    }
+    return 0;
+}
+
+long orc_mvdrn_stream(const short *pcm, long chan_stride, int n_mics, long n_blocks, const double *delays,
+                      double loading, short *out, double *pre_cast)
+{
+    const int M = n_mics, NB = MV_N / 2 + 1;
+    orc_cplx *x = (orc_cplx *)calloc(MV_N, sizeof(orc_cplx));
+    orc_cplx *X = (orc_cplx *)calloc((size_t)M * MV_N, sizeof(orc_cplx));
+    orc_cplx *Y = (orc_cplx *)calloc(MV_N, sizeof(orc_cplx)), *y = (orc_cplx *)calloc(MV_N, sizeof(orc_cplx));
+    double complex *R = (double complex *)calloc((size_t)NB * M * M, sizeof(double complex));
+    int iter = 0, count = 0;
+    long n_out = 0;
+    for (long b = 0; b < n_blocks; b++) {
+        const short *c0 = pcm + (size_t)b * MV_BLOCK;
+        if (!mvdr_vad(c0)) {
+            iter++;
+            if (iter > 1) {                       /* frame = [block b-1, block b] of every microphone */
+                for (int m = 0; m < M; m++) {
+                    const short *s = pcm + (size_t)m * chan_stride + (size_t)(b - 1) * MV_BLOCK;
+                    for (int i = 0; i < MV_N; i++) { x[i].re = s[i]; x[i].im = 0; }
+                    orc_dft_c2c(x, X + (size_t)m * MV_N, MV_N, -1);
+                }
+                for (int k = 0; k < NB; k++)
+                    for (int r = 0; r < M; r++)
+                        for (int c = 0; c < M; c++) {
+                            double complex xr = X[(size_t)r * MV_N + k].re + I * X[(size_t)r * MV_N + k].im;
+                            double complex xc = X[(size_t)c * MV_N + k].re + I * X[(size_t)c * MV_N + k].im;
+                            R[((size_t)k * M + r) * M + c] += xr * conj(xc) / MV_N;
+                        }
+            }
+        } else {
+            iter = 0;
+        }
+        count++;
+        for (int m = 0; m < M; m++) {
+            const short *s = pcm + (size_t)m * chan_stride + (size_t)b * MV_BLOCK;
+            memset(x, 0, sizeof(orc_cplx) * MV_N);
+            if (b > 0) for (int i = 0; i < MV_KEEP; i++) x[i].re = s[i - MV_BLOCK];     /* first 511 samples of block b-1 */
+            for (int i = 0; i < MV_BLOCK; i++) x[i + MV_KEEP].re = s[i];
+            orc_dft_c2c(x, X + (size_t)m * MV_N, MV_N, -1);
+        }
+        for (int k = 0; k < NB; k++) {
+            double complex A[MVN_MAX][MVN_MAX], cv[MVN_MAX], w[MVN_MAX];
+            double tr = 0;
+            for (int r = 0; r < M; r++) tr += creal(R[((size_t)k * M + r) * M + r]);
+            for (int r = 0; r < M; r++) {
+                for (int c = 0; c < M; c++) A[r][c] = R[((size_t)k * M + r) * M + c];
+                A[r][r] += loading * tr / M;
+                double ang = 2 * PI_APPS * k * (16000.0 / MV_N) * (delays ? delays[r] : 0.0);
+                cv[r] = cos(ang) + I * sin(ang);
+                w[r] = cv[r];
+            }
+            solve_cplx(M, A, w);
+            double complex den = 0;
+            for (int r = 0; r < M; r++) den += conj(cv[r]) * w[r];
+            double complex acc = 0;
+            for (int r = 0; r < M; r++) {
+                double complex xr = X[(size_t)r * MV_N + k].re + I * X[(size_t)r * MV_N + k].im;
+                acc += conj(w[r] / den) * xr;
+            }
+            Y[k].re = creal(acc); Y[k].im = cimag(acc);
+            if (k > 0 && k < MV_N / 2) { Y[MV_N - k].re = creal(acc); Y[MV_N - k].im = -cimag(acc); }
+        }
+        orc_dft_c2c(Y, y, MV_N, +1);
+        if (count > 1) {
+            for (int i = 0; i < MV_BLOCK; i++) {
+                double v = y[i + MV_KEEP].re * 1. / MV_N;
+                out[(size_t)n_out * MV_BLOCK + i] = cast_i16(v);
+                if (pre_cast) pre_cast[(size_t)n_out * MV_BLOCK + i] = v;
+            }
+            n_out++;
+        }
+    }
+    free(x); free(X); free(Y); free(y); free(R);
+    return n_out;
+}

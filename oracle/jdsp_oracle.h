@@ -121,6 +121,20 @@ void orc_pitch_stream(const short *pcm, long n_blocks, int *arg, double *rmax, d
 long orc_mvdr_stream(const short *left, const short *right, long n_blocks, double d_time,
                      short *out, double *pre_cast, double *corr4, double *corr_trace);
 
+/* BASELINE config 5 / SURVEY §8f rank 3: the MVDR beamformer generalised to n_mics <= 8 microphones
+ * with a PER-BIN n_mics x n_mics covariance.  NOT what the reference computes (it has 2 mics and
+ * one real 2x2 matrix summed over all bins, see orc_mvdr_stream): there is no reference for this
+ * function, it defines the generalisation ("parity unpinned" by construction).  Kept from the
+ * reference: 1024-point frames [first 511 samples of the previous block, block, 0] (:136-141,
+ * :195-196), the energy VAD on microphone 0 (:207-242), the run counter and the
+ * [previous block, block] estimation frames (:191-211,:250-253), R_k += X_k X_k^H / 1024 per noise
+ * frame, w_k = R_k^-1 c_k / (c_k^H R_k^-1 c_k) (:170-171) with c_k[m] = exp(j 2 PI f_k delay[m])
+ * (signed frequency, so the output is real), y = IDFT(w^H X), samples 511..1022 emitted, first
+ * block dropped (:201-204).  loading >= 0 adds loading * trace(R_k)/n_mics to R_k's diagonal.
+ * pcm: n_mics planes of chan_stride samples.  Returns blocks written. */
+long orc_mvdrn_stream(const short *pcm, long chan_stride, int n_mics, long n_blocks, const double *delays,
+                      double loading, short *out, double *pre_cast);
+
 #ifdef __cplusplus
 }
 #endif

@@ -67,6 +67,9 @@ class Oracle:
         L.orc_mvdr_stream.argtypes = [_c_short_p, _c_short_p, C.c_long, C.c_double, _c_short_p, _c_double_p,
                                       _c_double_p, _c_double_p]
         L.orc_mvdr_stream.restype = C.c_long
+        L.orc_mvdrn_stream.argtypes = [_c_short_p, C.c_long, C.c_int, C.c_long, _c_double_p, C.c_double, _c_short_p,
+                                       _c_double_p]
+        L.orc_mvdrn_stream.restype = C.c_long
         L.orc_mfcc_native_cfg.argtypes = [C.POINTER(MfccCfg)]
         L.orc_mel_init.argtypes = [C.POINTER(MfccCfg), _c_double_p, _c_int_p, _c_double_p]
         L.orc_mfcc_frame.argtypes = [C.POINTER(MfccCfg), _c_int_p, _c_double_p, _c_short_p, _c_double_p]
@@ -202,6 +205,18 @@ class Oracle:
         n = self.lib.orc_mvdr_stream(_p(left, _c_short_p), _p(right, _c_short_p), nb, d_time, _p(out, _c_short_p),
                                      _p(pre, _c_double_p), _p(corr, _c_double_p), _p(trace, _c_double_p))
         return out[:n * 512].copy(), pre[:n * 512].copy(), corr, trace[:nb]
+
+    def mvdrn_stream(self, pcm, delays=None, loading=0.0):
+        """pcm: int16 [n_mics, n_samples] (planar)."""
+        pcm = np.ascontiguousarray(pcm, np.int16)
+        m, n = pcm.shape
+        nb = n // 512
+        out = np.zeros(max(nb, 1) * 512, np.int16)
+        pre = np.zeros(max(nb, 1) * 512, np.float64)
+        d = np.ascontiguousarray(delays if delays is not None else np.zeros(m), np.float64)
+        k = self.lib.orc_mvdrn_stream(_p(pcm, _c_short_p), n, m, nb, _p(d, _c_double_p), float(loading),
+                                      _p(out, _c_short_p), _p(pre, _c_double_p))
+        return out[:k * 512].copy(), pre[:k * 512].copy()
 
     def mfcc_native_cfg(self):
         c = MfccCfg()

@@ -190,6 +190,23 @@ def main():
                "BeamForming_MVDR_ver1: VAD + correlation + per-bin weights + inverse, 65,536 stereo blocks",
                cpu=cpu_rate(lambda: orc.mvdr_stream(l[:512 * 512], r[:512 * 512]), 512))
         mv.close()
+    if on("mvdr8"):
+        nbm = 16384
+        mics = np.stack([pcm_of(rng, nbm * 512) for _ in range(8)])
+        mics[:, :40 * 512] = np.stack([pcm_of(rng, 40 * 512, 30.0) for _ in range(8)])
+        tm = torch.from_numpy(mics).cuda()
+        mv = eng.mvdr_multi(8, None, 1e-3)
+        mv.process(tm)
+
+        def step8():
+            mv.reset()
+            mv.process(tm)
+        ms = timed(step8, max(a.iters // 4, 3))
+        small = mics[:, :64 * 512].copy()
+        report("mvdr_8mic_per_bin_covariance", ms, nbm, "blocks", 8 * 1024 + 1024, 9 * 5 * 512 * 9 + 9 * 512 * 14 + 1024 * 8 * 8,
+               "BASELINE config 5 (generalisation, no reference): 8 microphones, per-bin 8x8 covariance, 16,384 blocks, 39 estimation frames",
+               cpu=cpu_rate(lambda: orc.mvdrn_stream(small, None, 1e-3), 64))
+        mv.close()
     eng.close()
 
 
