@@ -103,6 +103,7 @@ def main():
     ap.add_argument("--frames", type=int, default=FRAMES_PER_GPU, help="frames per GPU per step")
     ap.add_argument("--gather", action="store_true", help="also time an RCCL all_gather of the spectra (reported separately)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="time eager launches instead of one hipGraph replay of the K steps")
     args = ap.parse_args()
 
     import torch
@@ -138,13 +139,32 @@ def main():
     for _ in range(args.warmup):
         eng.stft(pcm, B, N_FFT, HOP, out=spec)
     barrier()
-    # Timed region: K back-to-back launches on the stream the kernels run on (torch's current
-    # stream, handed to the engine), bracketed by HIP events; wall clock bracketed by barriers.
+    # Timed region: EXACTLY K launches, captured once into a hipGraph (jdsp_stft_i16_dev only
+    # enqueues: no allocation, no sync) and replayed, so the host's per-launch overhead is not in
+    # the way; bracketed by HIP events on the launch stream and by barriers for the wall clock.
+    graph = None
+    if not args.no_graph:
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.stream(side):
+                with torch.cuda.graph(graph, stream=side):
+                    for _ in range(args.steps):
+                        eng.stft(pcm, B, N_FFT, HOP, out=spec)
+            torch.cuda.current_stream().wait_stream(side)
+        except Exception as exc:                      # capture unsupported: fall back to eager launches
+            print("bench: graph capture failed (%s), timing eager launches" % exc, file=sys.stderr)
+            graph = None
+    barrier()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     e0.record()
-    for _ in range(args.steps):
-        eng.stft(pcm, B, N_FFT, HOP, out=spec)
+    if graph is not None:
+        graph.replay()
+    else:
+        for _ in range(args.steps):
+            eng.stft(pcm, B, N_FFT, HOP, out=spec)
     e1.record()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -184,7 +204,8 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": "STFT analysis n_fft=1024 hop=512 Hamming, batch=%d frames/GPU, int16 PCM in HBM -> complex64 full spectrum in HBM" % B,
-                       "frames_per_gpu": B, "parallelism": "frame-sharded x%d, no collective" % world},
+                       "frames_per_gpu": B, "parallelism": "frame-sharded x%d, no collective" % world,
+                       "launch": "hipGraph replay of the K steps" if graph is not None else "eager"},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": read_traffic(),
                          "kernel": "stft1024_hop512_kernel<2>", "kernel_ms": kern_ms,
