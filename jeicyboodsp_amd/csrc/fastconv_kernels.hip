@@ -167,12 +167,34 @@ __device__ __forceinline__ float2 row_at(const float2 *rows, int k) { return row
 #ifndef JDSP_CONV8192_MINWAVES
 #define JDSP_CONV8192_MINWAVES 2
 #endif
-__global__ __launch_bounds__(512, JDSP_CONV8192_MINWAVES) void fastconv8192_kernel(ConvStream s, long n_out_blocks, int first_block, int block,
-                                                           int n_taps, int n_filters, const float2 *__restrict__ Hall,
-                                                           const float2 *__restrict__ table,
-                                                           const float2 *__restrict__ tw4096,
-                                                           const float2 *__restrict__ tw8192, short *__restrict__ out,
-                                                           float *__restrict__ precast, long plane)
+
+// split of the 4096-point packed transform + multiply by the filter spectrum + inverse
+// pre-split for bin m and its partner m + 4096 (the inverse transform's input layout)
+__device__ __forceinline__ void conv8192_bin(const float2 *rows, int m, const float2 *__restrict__ tw8192,
+                                             float2 &xl, float2 &xh)
+{
+    const float2 zm = row_at(rows, m), zc = row_at(rows, (4096 - m) & 4095);
+    const float2 ev = make_float2(zm.x + zc.x, zm.y - zc.y);
+    const float2 od = make_float2(zm.y + zc.y, zc.x - zm.x);
+    const float2 tt = cmul(tw8192[m], od);
+    xl = cadd(ev, tt);                        // X[m]
+    xh = csub(ev, tt);                        // X[m + 4096]
+}
+
+__device__ __forceinline__ float2 conv8192_mul(float2 xl, float2 xh, int m, const float2 *__restrict__ H,
+                                               const float2 *__restrict__ tw8192)
+{
+    const float2 yl = cmul(xl, H[m]), yh = cmul(xh, H[m + 4096]);     // :150-151
+    const float2 sm = cadd(yl, yh);
+    const float2 df = cmul_conj(csub(yl, yh), tw8192[m]);
+    return make_float2(sm.x - df.y, sm.y + df.x);
+}
+
+template <bool SINGLE>
+__global__ __launch_bounds__(512, JDSP_CONV8192_MINWAVES) void fastconv8192_kernel(
+    ConvStream s, long n_out_blocks, int first_block, int block, int n_taps, int n_filters,
+    const float2 *__restrict__ Hall, const float2 *__restrict__ table, const float2 *__restrict__ tw4096,
+    const float2 *__restrict__ tw8192, short *__restrict__ out, float *__restrict__ precast, long plane)
 {
     __shared__ __attribute__((aligned(16))) float2 rows[8 * kRow];
     const int t = threadIdx.x, l = t & 63;
@@ -181,36 +203,47 @@ __global__ __launch_bounds__(512, JDSP_CONV8192_MINWAVES) void fastconv8192_kern
     WaveTwiddles tw;
     load_wave_twiddles(tw, table, l);
     float2 v[8];
+    // common case (workgroup-uniform): the whole segment is inside this call's buffer, past the
+    // stream's silent head and 4-byte aligned -> one dword per sample pair, no per-sample tests
+    const long seg0 = end - 8192;
+    if (seg0 >= 0 && end <= s.n_samples && seg0 + s.global0 >= s.valid_from && (((uintptr_t)(s.pcm + seg0)) & 3u) == 0) {
+        const unsigned int *src = reinterpret_cast<const unsigned int *>(s.pcm + seg0) + t;
 #pragma unroll
-    for (int r = 0; r < 8; r++) {
-        const long p0 = end - 8192 + 2 * (t + 512 * r);
-        v[r] = make_float2(0.5f * conv_sample(s, p0), 0.5f * conv_sample(s, p0 + 1));
+        for (int r = 0; r < 8; r++) {
+            const float2 p = unpack_i16x2(src[512 * r]);
+            v[r] = make_float2(0.5f * p.x, 0.5f * p.y);
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const long p0 = seg0 + 2 * (t + 512 * r);
+            v[r] = make_float2(0.5f * conv_sample(s, p0), 0.5f * conv_sample(s, p0 + 1));
+        }
     }
     wg_fft4096<false>(v, rows, t, tw4096, tw);
-    // split + multiply + inverse pre-split, per m = t + 512 r (the inverse transform's input layout)
-    float2 xl[8], xh[8];
-#pragma unroll
-    for (int r = 0; r < 8; r++) {
-        const int m = t + 512 * r;
-        const float2 zm = row_at(rows, m), zc = row_at(rows, (4096 - m) & 4095);
-        const float2 ev = make_float2(zm.x + zc.x, zm.y - zc.y);
-        const float2 od = make_float2(zm.y + zc.y, zc.x - zm.x);
-        const float2 tt = cmul(tw8192[m], od);
-        xl[r] = cadd(ev, tt);                        // X[m]
-        xh[r] = csub(ev, tt);                        // X[m + 4096]
-    }
-    for (int f = 0; f < n_filters; f++) {
-        const float2 *H = Hall + (size_t)f * 8192;
+    if (SINGLE) {
         float2 y[8];
 #pragma unroll
         for (int r = 0; r < 8; r++) {
             const int m = t + 512 * r;
-            const float2 yl = cmul(xl[r], H[m]), yh = cmul(xh[r], H[m + 4096]);     // :150-151
-            const float2 sm = cadd(yl, yh);
-            const float2 df = cmul_conj(csub(yl, yh), tw8192[m]);
-            y[r] = make_float2(sm.x - df.y, sm.y + df.x);
+            float2 xl, xh;
+            conv8192_bin(rows, m, tw8192, xl, xh);
+            y[r] = conv8192_mul(xl, xh, m, Hall, tw8192);
         }
         wg_fft4096<true>(y, rows, t, tw4096, tw);
+    }
+    float2 xl[SINGLE ? 1 : 8], xh[SINGLE ? 1 : 8];
+    if (!SINGLE) {
+#pragma unroll
+        for (int r = 0; r < 8; r++) conv8192_bin(rows, t + 512 * r, tw8192, xl[r], xh[r]);
+    }
+    for (int f = 0; f < n_filters; f++) {
+        if (!SINGLE) {
+            float2 y[8];
+#pragma unroll
+            for (int r = 0; r < 8; r++) y[r] = conv8192_mul(xl[r], xh[r], t + 512 * r, Hall + (size_t)f * 8192, tw8192);
+            wg_fft4096<true>(y, rows, t, tw4096, tw);
+        }
         // rows[k1][k2] = z'[k1 + 8 k2] = (y[2n], y[2n+1]) * 8192, n = k1 + 8 k2; keep samples n_taps-1 .. 8191
         short *o = out + (size_t)f * plane + e * block;
         float *pc = precast ? precast + (size_t)f * plane + e * block : nullptr;
@@ -239,8 +272,11 @@ int launch_fastconv(hipStream_t st, int n_fft, const ConvStream &s, long n_out_b
         if (n_fft == 1024)
             hipLaunchKernelGGL(fastconv1024_kernel, dim3((unsigned)n_out_blocks), dim3(64), 0, st, s, n_out_blocks,
                                first_block, block, n_taps, n_filters, H, table, out, precast, plane);
+        else if (n_filters == 1)
+            hipLaunchKernelGGL(fastconv8192_kernel<true>, dim3((unsigned)n_out_blocks), dim3(512), 0, st, s, n_out_blocks,
+                               first_block, block, n_taps, n_filters, H, table, tw4096, tw8192, out, precast, plane);
         else
-            hipLaunchKernelGGL(fastconv8192_kernel, dim3((unsigned)n_out_blocks), dim3(512), 0, st, s, n_out_blocks,
+            hipLaunchKernelGGL(fastconv8192_kernel<false>, dim3((unsigned)n_out_blocks), dim3(512), 0, st, s, n_out_blocks,
                                first_block, block, n_taps, n_filters, H, table, tw4096, tw8192, out, precast, plane);
     }
     if (s.hist_len > 0)
