@@ -119,16 +119,18 @@ __global__ __launch_bounds__(64) void mfcc_kernel(const short *__restrict__ pcm,
     wave_lds_fence();
     if (lane < p.n_chan) logmel[lane] = logf(logmel[lane]);               // :171
     wave_lds_fence();
-    // DCT-II (:178-182) and lifter (:189)
-    if (lane < p.n_cep) {
-        double c0 = 0.0, c1 = 0.0;
-        int k = 0;
-        for (; k + 2 <= p.n_chan; k += 2) {
-            c0 += p.dct[k * 32 + lane] * (double)logmel[k];
-            c1 += p.dct[(k + 1) * 32 + lane] * (double)logmel[k + 1];
+    // DCT-II (:178-182) and lifter (:189): cepstrum i on lanes i, i+16, i+32, i+48, each summing every
+    // fourth channel (four short independent chains of table loads instead of one long one)
+    {
+        const int i = lane & 15, part = lane >> 4;
+        double acc = 0.0;
+        if (i < p.n_cep) {
+#pragma unroll 4
+            for (int k = part; k < p.n_chan; k += 4) acc += p.dct[k * 32 + i] * (double)logmel[k];
         }
-        if (k < p.n_chan) c0 += p.dct[k * 32 + lane] * (double)logmel[k];
-        feats[f * p.n_cep + lane] = (c0 + c1) * p.lifter_w[lane];
+        acc += __shfl_xor(acc, 16);
+        acc += __shfl_xor(acc, 32);
+        if (lane < p.n_cep) feats[f * p.n_cep + lane] = acc * p.lifter_w[lane];
     }
 }
 

@@ -240,10 +240,7 @@ int launch_stft512(hipStream_t stream, int n_cu, const short *pcm, long n_frames
                    const float2 *table, const float2 *win512)
 {
     if (n_frames <= 0) return 0;
-    long target_waves = (long)n_cu * 32;
-    long fpw = (n_frames + target_waves - 1) / target_waves;
-    if (fpw > 8) fpw = 8;
-    if (fpw < 1) fpw = 1;
+    const long fpw = n_frames >= 2L * n_cu * 16 ? 2 : 1;
     const long grid = (n_frames + fpw - 1) / fpw;
     hipLaunchKernelGGL(stft512_kernel, dim3((unsigned)grid), dim3(64), 0, stream, pcm, spec, n_frames, (int)fpw, hop,
                        table, win512);
@@ -283,10 +280,9 @@ int launch_stft1024(hipStream_t stream, int n_cu, int fpw_opt, const short *pcm,
         default: launch_hop512<JDSP_STFT_K>(stream, pcm, n_frames, spec, table); break;
         }
     } else {
-        long target_waves = (long)n_cu * 16;
-        long fpw = (n_frames + target_waves - 1) / target_waves;
-        if (fpw > 16) fpw = 16;
-        if (fpw < 1) fpw = 1;
+        // short-lived waves here too: a wave that loops reads its next frame after its stores
+        // and so waits for them (see the header); two frames amortise the table loads
+        const long fpw = n_frames >= 2L * n_cu * 16 ? 2 : 1;
         long grid = (n_frames + fpw - 1) / fpw;
         hipLaunchKernelGGL(stft1024_anyhop_kernel, dim3((unsigned)grid), dim3(64), 0, stream, pcm, spec, n_frames,
                            (int)fpw, hop, table);
