@@ -87,6 +87,30 @@ __device__ __forceinline__ void relayout_half(unsigned int *stage, int lane, u32
     wave_lds_fence();
 }
 
+// BeamForming_MVDR_ver1.cpp's frame (:136-141,:195-196): [first 511 samples of the previous block,
+// block, 0].  `img_prev` / `img_cur` are the two blocks as 16-byte-per-lane load images; they are
+// laid side by side in LDS (stage: 1024 + 8 shorts) and every lane picks its eight sample pairs
+// (2 lane + 128 r, +1), r < 8: position p reads the buffer at p for p < 511 and at p + 1 after.
+__device__ __forceinline__ void mvdr_frame_pairs(unsigned int *stage32, int lane, u32x4 img_prev, u32x4 img_cur,
+                                                 float2 (&v)[8], float scale)
+{
+    reinterpret_cast<u32x4 *>(stage32)[lane] = img_prev;
+    reinterpret_cast<u32x4 *>(stage32)[64 + lane] = img_cur;
+    if (lane == 0) stage32[512] = 0u;
+    wave_lds_fence();
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const int p = 2 * lane + 128 * r;
+        const unsigned int a = stage32[p >> 1], b = stage32[(p >> 1) + 1];
+        float x0, x1;
+        if (p < 510) { x0 = (float)(short)(a & 0xffffu); x1 = (float)((int)a >> 16); }
+        else if (p == 510) { x0 = (float)(short)(a & 0xffffu); x1 = (float)(short)(b & 0xffffu); }
+        else { x0 = (float)((int)a >> 16); x1 = p == 1022 ? 0.f : (float)(short)(b & 0xffffu); }
+        v[r] = make_float2(scale * x0, scale * x1);
+    }
+    wave_lds_fence();
+}
+
 // Which estimate applies to block j, from plan_kernel's per-64-block summaries
 // (denoise_kernels.hip): the count of latches at or before j.
 __device__ __forceinline__ int version_of(const int *__restrict__ ver_base,

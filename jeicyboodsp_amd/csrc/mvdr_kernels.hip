@@ -124,16 +124,6 @@ __global__ void mvdr_prefix_kernel(const double *__restrict__ delta, const Denoi
     if (total) total[c] = sum;
 }
 
-// frame position p of block j: [first 511 samples of block j-1, block j, 0]  (:136-141,:195-196)
-__device__ __forceinline__ float mvdr_sample(const short *__restrict__ pcm, const short *__restrict__ prev, long j,
-                                             bool have_prev, int p)
-{
-    if (p >= 1023) return 0.f;
-    if (p >= 511) return (float)pcm[j * 512 + (p - 511)];
-    if (!have_prev) return 0.f;                                     // keep buffer of the very first call: zeros
-    return j > 0 ? (float)pcm[(j - 1) * 512 + p] : (float)prev[p];
-}
-
 __global__ __launch_bounds__(64) void mvdr_kernel(const short *__restrict__ left, const short *__restrict__ right,
                                                   long n_blocks, long calls_before,
                                                   const MvdrState *__restrict__ st_in, MvdrState *st_out,
@@ -145,6 +135,7 @@ __global__ __launch_bounds__(64) void mvdr_kernel(const short *__restrict__ left
 {
     __shared__ __attribute__((aligned(16))) float2 lds[kWaveLdsComplex];
     __shared__ __attribute__((aligned(16))) float2 merged[1024];
+    __shared__ __attribute__((aligned(16))) unsigned int stage32[520];
     const int lane = threadIdx.x;
     const long per_xcd = (gridDim.x + 7) >> 3;
     const long j = (long)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
@@ -155,19 +146,13 @@ __global__ __launch_bounds__(64) void mvdr_kernel(const short *__restrict__ left
     const bool have_prev = calls_before + j > 0;
 
     float2 llo[8], lhi[8], rlo[8], rhi[8], v[8];
-#pragma unroll
-    for (int r = 0; r < 8; r++) {
-        const int p = 2 * lane + 128 * r;
-        v[r] = make_float2(0.5f * mvdr_sample(left, st_in->prev_l, j, have_prev, p),
-                           0.5f * mvdr_sample(left, st_in->prev_l, j, have_prev, p + 1));
-    }
+    // keep buffer of a stream's very first block: zeros (:130-131); otherwise the previous block
+    const long jp = have_prev ? j - 1 : -2;
+    mvdr_frame_pairs(stage32, lane, mvdr_load_block(left, n_blocks, st_in->prev_l, jp, lane),
+                     mvdr_load_block(left, n_blocks, st_in->prev_l, j, lane), v, 0.5f);
     spectrum_of(v, lds, lane, tw, wsp, llo, lhi);
-#pragma unroll
-    for (int r = 0; r < 8; r++) {
-        const int p = 2 * lane + 128 * r;
-        v[r] = make_float2(0.5f * mvdr_sample(right, st_in->prev_r, j, have_prev, p),
-                           0.5f * mvdr_sample(right, st_in->prev_r, j, have_prev, p + 1));
-    }
+    mvdr_frame_pairs(stage32, lane, mvdr_load_block(right, n_blocks, st_in->prev_r, jp, lane),
+                     mvdr_load_block(right, n_blocks, st_in->prev_r, j, lane), v, 0.5f);
     spectrum_of(v, lds, lane, tw, wsp, rlo, rhi);
 
     // mxAutoCorr.inverse() (:170) for the matrix in effect at this block

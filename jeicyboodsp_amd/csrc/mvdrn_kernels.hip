@@ -144,16 +144,6 @@ __global__ __launch_bounds__(64) void mvdrn_update_kernel(const float2 *__restri
     cov_out[(size_t)k * 64 + lane] = make_double2(R.x, R.y);
 }
 
-// frame position p of block j for one channel: [first 511 samples of block j-1, block j, 0]
-__device__ __forceinline__ float mvn_sample(const short *__restrict__ chan, const short *__restrict__ prev, long j,
-                                            bool have_prev, int p)
-{
-    if (p >= 1023) return 0.f;
-    if (p >= 511) return (float)chan[j * 512 + (p - 511)];
-    if (!have_prev) return 0.f;
-    return j > 0 ? (float)chan[(j - 1) * 512 + p] : (float)prev[p];
-}
-
 __global__ __launch_bounds__(64) void mvdrn_apply_kernel(const short *__restrict__ pcm, long chan_stride, int n_mics,
                                                          long n_blocks, long calls_before,
                                                          const short *__restrict__ prev_in, short *__restrict__ prev_out,
@@ -164,6 +154,7 @@ __global__ __launch_bounds__(64) void mvdrn_apply_kernel(const short *__restrict
                                                          float *__restrict__ precast)
 {
     __shared__ __attribute__((aligned(16))) float2 lds[kWaveLdsComplex];
+    __shared__ __attribute__((aligned(16))) unsigned int stage32[520];
     const int lane = threadIdx.x;
     const long per_xcd = (gridDim.x + 7) >> 3;
     const long j = (long)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
@@ -181,11 +172,8 @@ __global__ __launch_bounds__(64) void mvdrn_apply_kernel(const short *__restrict
         const short *chan = pcm + (size_t)m * chan_stride;
         const short *prev = prev_in + (size_t)m * 512;
         float2 v[8], lo[8], hi[8];
-#pragma unroll
-        for (int r = 0; r < 8; r++) {
-            const int p = 2 * lane + 128 * r;
-            v[r] = make_float2(0.5f * mvn_sample(chan, prev, j, have_prev, p), 0.5f * mvn_sample(chan, prev, j, have_prev, p + 1));
-        }
+        mvdr_frame_pairs(stage32, lane, mvn_block(chan, n_blocks, prev, have_prev ? j - 1 : -2, lane),
+                         mvn_block(chan, n_blocks, prev, j, lane), v, 0.5f);
         mvn_spectrum(v, lds, lane, tw, wsp, lo, hi);
 #pragma unroll
         for (int q = 0; q < 8; q++) {
