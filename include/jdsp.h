@@ -71,6 +71,11 @@ int jdsp_malloc(jdsp_ctx *ctx, size_t bytes, void **dev_ptr);
 int jdsp_free(jdsp_ctx *ctx, void *dev_ptr);
 int jdsp_memcpy_h2d(jdsp_ctx *ctx, void *dev_dst, const void *host_src, size_t bytes);
 int jdsp_memcpy_d2h(jdsp_ctx *ctx, void *host_dst, const void *dev_src, size_t bytes);
+/* Page-locked host memory.  Host-pointer entry points given PINNED buffers (these, or any
+ * hipHostMalloc/hipHostRegister memory) overlap the PCIe copies with the kernels: jdsp_stft_i16
+ * then streams the batch through in chunks on three HIP streams (copy in | transform | copy out). */
+int jdsp_host_alloc(jdsp_ctx *ctx, size_t bytes, void **host_ptr);
+int jdsp_host_free(jdsp_ctx *ctx, void *host_ptr);
 
 /* ---- FFTAlgorithm_ver2.cpp -------------------------------------------------- */
 /* Bitrev table (FFTAlgorithm_ver2.cpp:186-202), computed on the device with the

@@ -51,6 +51,8 @@ def _load():
         "jdsp_device_info": (i, [vp, C.POINTER(i), C.POINTER(sz), C.c_char_p, sz]),
         "jdsp_malloc": (i, [vp, sz, C.POINTER(vp)]),
         "jdsp_free": (i, [vp, vp]),
+        "jdsp_host_alloc": (i, [vp, sz, C.POINTER(vp)]),
+        "jdsp_host_free": (i, [vp, vp]),
         "jdsp_memcpy_h2d": (i, [vp, vp, vp, sz]),
         "jdsp_memcpy_d2h": (i, [vp, vp, vp, sz]),
         "jdsp_bitrev_table": (i, [vp, i, i, vp]),

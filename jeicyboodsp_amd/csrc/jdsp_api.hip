@@ -90,6 +90,12 @@ int jdsp_destroy(jdsp_ctx *ctx)
         if (p) (void)hipFree(p);
     if (ctx->vad_w_hi) (void)hipFree(ctx->vad_w_hi);
     if (ctx->win512) (void)hipFree(ctx->win512);
+    for (auto &p : ctx->pipe_buf)
+        if (p) (void)hipFree(p);
+    for (auto &ev : ctx->pipe_ev)
+        if (ev) (void)hipEventDestroy(ev);
+    if (ctx->pipe_in) (void)hipStreamDestroy(ctx->pipe_in);
+    if (ctx->pipe_out) (void)hipStreamDestroy(ctx->pipe_out);
     if (ctx->conv_tw4096) (void)hipFree(ctx->conv_tw4096);
     if (ctx->conv_tw8192) (void)hipFree(ctx->conv_tw8192);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -154,6 +160,22 @@ int jdsp_free(jdsp_ctx *ctx, void *dev_ptr)
 {
     if (!ctx) return JDSP_EINVAL;
     JDSP_HIP(ctx, hipFree(dev_ptr));
+    return JDSP_OK;
+}
+
+int jdsp_host_alloc(jdsp_ctx *ctx, size_t bytes, void **host_ptr)
+{
+    if (!ctx || !host_ptr) return JDSP_EINVAL;
+    JDSP_HIP(ctx, hipSetDevice(ctx->device));
+    hipError_t e = hipHostMalloc(host_ptr, bytes ? bytes : 1, hipHostMallocDefault);
+    if (e != hipSuccess) return fail(ctx, JDSP_ENOMEM, "jdsp_host_alloc", e);
+    return JDSP_OK;
+}
+
+int jdsp_host_free(jdsp_ctx *ctx, void *host_ptr)
+{
+    if (!ctx) return JDSP_EINVAL;
+    JDSP_HIP(ctx, hipHostFree(host_ptr));
     return JDSP_OK;
 }
 
@@ -333,6 +355,68 @@ int jdsp_stft_i16_dev(jdsp_ctx *ctx, const int16_t *pcm_dev, long n_frames, int 
     return JDSP_OK;
 }
 
+static bool is_pinned_host(const void *p)
+{
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+        (void)hipGetLastError();               // an ordinary (pageable) pointer is not an error
+        return false;
+    }
+    return a.type == hipMemoryTypeHost;
+}
+
+// Pinned buffers: the batch goes through in chunks of kPipeFrames frames, double-buffered on the
+// device, with the copy-in of chunk c+1 and the copy-out of chunk c-1 running beside the
+// transform of chunk c (three streams, events for the hand-offs).
+static int stft_pipelined(jdsp_ctx *ctx, const int16_t *pcm_host, long n_frames, int n_fft, int hop, jdsp_c32 *spec_host)
+{
+    const long kPipeFrames = 4096;
+    hipError_t e = hipSuccess;
+    if (!ctx->pipe_in) {
+        e = hipStreamCreateWithFlags(&ctx->pipe_in, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->pipe_out, hipStreamNonBlocking);
+        for (int i = 0; i < 6 && e == hipSuccess; i++) e = hipEventCreateWithFlags(&ctx->pipe_ev[i], hipEventDisableTiming);
+        if (e != hipSuccess) return fail(ctx, JDSP_EHIP, "stft pipeline: streams", e);
+    }
+    const size_t in_cap = sizeof(int16_t) * (size_t)(kPipeFrames * hop + n_fft), out_cap = sizeof(jdsp_c32) * (size_t)kPipeFrames * n_fft;
+    for (int b = 0; b < 4; b++) {
+        const size_t want = b < 2 ? in_cap : out_cap;
+        if (ctx->pipe_cap[b] < want) {
+            if (ctx->pipe_buf[b]) (void)hipFree(ctx->pipe_buf[b]);
+            ctx->pipe_buf[b] = nullptr;
+            ctx->pipe_cap[b] = 0;
+            if ((e = hipMalloc(&ctx->pipe_buf[b], want)) != hipSuccess) return fail(ctx, JDSP_ENOMEM, "stft pipeline: buffers", e);
+            ctx->pipe_cap[b] = want;
+        }
+    }
+    hipEvent_t *ev_in = ctx->pipe_ev, *ev_comp = ctx->pipe_ev + 2, *ev_out = ctx->pipe_ev + 4;
+    hipStream_t comp = ctx->stream;
+    int rc = JDSP_OK;
+    long c = 0;
+    for (long f0 = 0; f0 < n_frames && !rc; f0 += kPipeFrames, c++) {
+        const int b = (int)(c & 1);
+        const long nf = n_frames - f0 < kPipeFrames ? n_frames - f0 : kPipeFrames;
+        int16_t *d_in = (int16_t *)ctx->pipe_buf[b];
+        jdsp_c32 *d_out = (jdsp_c32 *)ctx->pipe_buf[2 + b];
+        if (c >= 2) e = hipStreamWaitEvent(ctx->pipe_in, ev_comp[b], 0);          // the transform that read d_in is done
+        if (e == hipSuccess) e = hipMemcpyAsync(d_in, pcm_host + f0 * hop, sizeof(int16_t) * (size_t)((nf - 1) * hop + n_fft), hipMemcpyHostToDevice, ctx->pipe_in);
+        if (e == hipSuccess) e = hipEventRecord(ev_in[b], ctx->pipe_in);
+        if (e == hipSuccess) e = hipStreamWaitEvent(comp, ev_in[b], 0);
+        if (e == hipSuccess && c >= 2) e = hipStreamWaitEvent(comp, ev_out[b], 0);    // d_out has been copied out
+        if (e != hipSuccess) { rc = fail(ctx, JDSP_EHIP, "stft pipeline: copy in", e); break; }
+        rc = jdsp_stft_i16_dev(ctx, d_in, nf, n_fft, hop, d_out);
+        if (rc) break;
+        e = hipEventRecord(ev_comp[b], comp);
+        if (e == hipSuccess) e = hipStreamWaitEvent(ctx->pipe_out, ev_comp[b], 0);
+        if (e == hipSuccess) e = hipMemcpyAsync(spec_host + (size_t)f0 * n_fft, d_out, sizeof(jdsp_c32) * (size_t)nf * n_fft, hipMemcpyDeviceToHost, ctx->pipe_out);
+        if (e == hipSuccess) e = hipEventRecord(ev_out[b], ctx->pipe_out);
+        if (e != hipSuccess) rc = fail(ctx, JDSP_EHIP, "stft pipeline: copy out", e);
+    }
+    hipError_t e1 = hipStreamSynchronize(ctx->pipe_in), e2 = hipStreamSynchronize(comp), e3 = hipStreamSynchronize(ctx->pipe_out);
+    if (!rc && (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess)) rc = fail(ctx, JDSP_EHIP, "stft pipeline: sync", e1 != hipSuccess ? e1 : (e2 != hipSuccess ? e2 : e3));
+    return rc;
+}
+
 int jdsp_stft_i16(jdsp_ctx *ctx, const int16_t *pcm_host, long n_samples, int n_fft, int hop, jdsp_c32 *spec_host,
                   long *n_frames_out)
 {
@@ -343,6 +427,8 @@ int jdsp_stft_i16(jdsp_ctx *ctx, const int16_t *pcm_host, long n_samples, int n_
     if (n_frames == 0) return JDSP_OK;
     if (!pcm_host || !spec_host) return fail(ctx, JDSP_EINVAL, "jdsp_stft_i16: NULL buffer");
     JDSP_HIP(ctx, hipSetDevice(ctx->device));
+    if (n_frames > 4096 && (((long)hop * 4096 * 2) & 15) == 0 && is_pinned_host(pcm_host) && is_pinned_host(spec_host))
+        return stft_pipelined(ctx, pcm_host, n_frames, n_fft, hop, spec_host);
     const size_t in_bytes = sizeof(int16_t) * (size_t)((n_frames - 1) * hop + n_fft);
     const size_t out_bytes = sizeof(jdsp_c32) * (size_t)n_frames * (size_t)n_fft;
     int16_t *d_in = nullptr;

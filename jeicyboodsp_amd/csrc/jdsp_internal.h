@@ -26,6 +26,11 @@ struct jdsp_ctx {
     double2 *c2c_tw[16] = {nullptr};   // by log2(n_fft)
     float2 *conv_tw4096 = nullptr, *conv_tw8192 = nullptr;
     double *vad_w_hi = nullptr;        // second half of the FP64 Hamming window
+    // pinned-host pipeline of jdsp_stft_i16: copy-in / compute / copy-out on three streams
+    hipStream_t pipe_in = nullptr, pipe_out = nullptr;
+    hipEvent_t pipe_ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    void *pipe_buf[4] = {nullptr, nullptr, nullptr, nullptr};   // in[2], out[2]
+    size_t pipe_cap[4] = {0, 0, 0, 0};
 };
 
 namespace jdsp {

@@ -151,7 +151,11 @@ class Engine:
         nf = C.c_long()
         total = pcm.size
         want = (total - n_fft) // hop + 1 if total >= n_fft else 0
-        res = np.empty((max(want, 0), n_fft), np.complex64)
+        if out is not None:              # e.g. a pinned buffer: the library then pipelines the PCIe copies
+            res = out
+            assert res.dtype == np.complex64 and res.flags.c_contiguous and res.shape == (max(want, 0), n_fft)
+        else:
+            res = np.empty((max(want, 0), n_fft), np.complex64)
         self._ck(L.jdsp_stft_i16(self._h, pcm.ctypes.data_as(C.c_void_p), total, n_fft, hop,
                                  res.ctypes.data_as(C.c_void_p), C.byref(nf)))
         assert nf.value == want

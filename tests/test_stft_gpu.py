@@ -113,3 +113,19 @@ def test_stft_full_batch_properties(eng):
     part = eng.stft(d[512 * lo: 512 * (lo + 8 + 1)], 8)
     torch.cuda.synchronize()
     assert torch.equal(part, spec[lo:lo + 8])
+
+
+def test_stft_pinned_host_buffers_take_the_pipelined_path(eng, oracle):
+    """Pinned host memory: chunks of 4,096 frames on three streams; same bits as the plain path."""
+    import torch
+    n_frames = 3 * 4096 + 77
+    pcm = _pcm(5, 512 * (n_frames + 1))
+    plain = eng.stft(pcm)
+    pin_in = torch.empty(pcm.size, dtype=torch.int16).pin_memory()
+    pin_in.numpy()[:] = pcm
+    pin_out = torch.empty((n_frames, 1024), dtype=torch.complex64).pin_memory()
+    got = eng.stft(pin_in.numpy(), out=pin_out.numpy())
+    assert np.array_equal(got, plain)
+    idx = np.r_[0:8, 4090:4100, 8190:8200, n_frames - 8:n_frames]
+    want = np.stack([oracle.stft(pcm[512 * f:512 * f + 1024], 1)[0] for f in idx])
+    _check(got[idx].astype(np.complex128), want)

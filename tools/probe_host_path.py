@@ -17,3 +17,16 @@ for _ in range(3):
     ts.append(time.perf_counter() - t0)
 print("host path: %.1f ms per 65,536 frames (best of 3) = %.2f M frames/s; output %.0f MiB"
       % (min(ts) * 1e3, B / min(ts) / 1e6, spec.nbytes / 2**20))
+
+import torch
+pin_in = torch.empty(pcm.size, dtype=torch.int16).pin_memory()
+pin_in.numpy()[:] = pcm
+pin_out = torch.empty((B, 1024), dtype=torch.complex64).pin_memory()
+eng.stft(pin_in.numpy(), out=pin_out.numpy())
+ts = []
+for _ in range(3):
+    t0 = time.perf_counter()
+    eng.stft(pin_in.numpy(), out=pin_out.numpy())
+    ts.append(time.perf_counter() - t0)
+print("pinned, pipelined: %.1f ms per 65,536 frames (best of 3) = %.2f M frames/s; equal to the plain path: %s"
+      % (min(ts) * 1e3, B / min(ts) / 1e6, np.array_equal(pin_out.numpy(), spec)))
