@@ -102,6 +102,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--frames", type=int, default=FRAMES_PER_GPU, help="frames per GPU per step")
     ap.add_argument("--gather", action="store_true", help="also time an RCCL all_gather of the spectra (reported separately)")
+    ap.add_argument("--no-gather", action="store_true", help="skip the (separately reported) output all_gather at N > 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="time eager launches instead of one hipGraph replay of the K steps")
     args = ap.parse_args()
@@ -170,21 +171,29 @@ def main():
     elapsed = time.perf_counter() - t0
     kern_ms = e0.elapsed_time(e1) / max(args.steps, 1)      # average launch duration (incl. launch gaps)
 
+    # The only collective of the path: gathering the spectra (RCCL all_gather over xGMI).  Timed
+    # AFTER and OUTSIDE the timed region, reported separately, never part of `value` (SURVEY §5:
+    # at 8 GPUs it costs far more than the transform).  On by default when there is more than one rank.
     gather_ms = None
-    if args.gather and dist is not None:
-        from jeicyboodsp_amd import sharding
-        sharding.all_gather_rows(spec, [B] * world, dist)
-        barrier()
-        t1 = time.perf_counter()
-        for _ in range(5):
+    if dist is not None and (args.gather or (world > 1 and not args.no_gather)):
+        try:
+            from jeicyboodsp_amd import sharding
             sharding.all_gather_rows(spec, [B] * world, dist)
-        barrier()
-        gather_ms = (time.perf_counter() - t1) / 5 * 1e3
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(3):
+                sharding.all_gather_rows(spec, [B] * world, dist)
+            barrier()
+            gather_ms = (time.perf_counter() - t1) / 3 * 1e3
+        except Exception as exc:
+            print("bench: output gather skipped (%s)" % exc, file=sys.stderr)
+            gather_ms = None
 
-    t = torch.tensor([elapsed, kern_ms], dtype=torch.float64, device=dev)
+    t = torch.tensor([elapsed, kern_ms, gather_ms if gather_ms is not None else -1.0], dtype=torch.float64, device=dev)
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed, kern_ms = float(t[0]), float(t[1])
+    gather_ms = float(t[2]) if float(t[2]) >= 0 else None
 
     if rank == 0:
         frames_total = float(B) * world * args.steps
