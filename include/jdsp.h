@@ -60,7 +60,10 @@ const char *jdsp_last_error(const jdsp_ctx *ctx);   /* ctx may be NULL: global c
 int jdsp_set_stream(jdsp_ctx *ctx, void *hip_stream);
 int jdsp_use_own_stream(jdsp_ctx *ctx);
 /* Tuning knobs, by name; unknown names return JDSP_EINVAL.
- *   "stft.frames_per_wave"  consecutive frames one wavefront owns (0 = auto) */
+ *   "stft.frames_per_wave"  consecutive frames one wavefront owns (0 = auto)
+ *   "stft.window"           window of jdsp_stft_*: 0 = the reference's Hamming
+ *                           0.54-0.46cos(2*3.141592*i/(n-1)) (default), 1 = Hann 0.5-0.5cos(same).
+ *                           The denoise / MFCC / pitch chains always use what the reference uses. */
 int jdsp_set_option(jdsp_ctx *ctx, const char *name, long value);
 int jdsp_synchronize(jdsp_ctx *ctx);
 /* Device properties the host side sizes launches with. */

@@ -22,7 +22,7 @@ int ensure_stft1024_table(jdsp_ctx *ctx)
     if (ctx->stft1024_table) return 0;
     const int n = stft1024_table_count();
     std::vector<float2> host((size_t)n);
-    fill_stft1024_table(host.data());
+    fill_stft1024_table(host.data(), 0);
     JDSP_HIP(ctx, hipMalloc((void **)&ctx->stft1024_table, sizeof(float2) * (size_t)n));
     JDSP_HIP(ctx, hipMemcpy(ctx->stft1024_table, host.data(), sizeof(float2) * (size_t)n, hipMemcpyHostToDevice));
     return 0;
@@ -90,6 +90,8 @@ int jdsp_destroy(jdsp_ctx *ctx)
         if (p) (void)hipFree(p);
     if (ctx->vad_w_hi) (void)hipFree(ctx->vad_w_hi);
     if (ctx->win512) (void)hipFree(ctx->win512);
+    if (ctx->win512_hann) (void)hipFree(ctx->win512_hann);
+    if (ctx->stft1024_table_hann) (void)hipFree(ctx->stft1024_table_hann);
     for (auto &p : ctx->pipe_buf)
         if (p) (void)hipFree(p);
     for (auto &ev : ctx->pipe_ev)
@@ -125,6 +127,11 @@ int jdsp_set_option(jdsp_ctx *ctx, const char *name, long value)
     if (!strcmp(name, "stft.frames_per_wave")) {
         if (value < 0 || value > 4096) return fail(ctx, JDSP_EINVAL, "stft.frames_per_wave out of range");
         ctx->opt_stft_fpw = (int)value;
+        return JDSP_OK;
+    }
+    if (!strcmp(name, "stft.window")) {
+        if (value != 0 && value != 1) return fail(ctx, JDSP_EINVAL, "stft.window: 0 (Hamming) or 1 (Hann)");
+        ctx->opt_stft_window = (int)value;
         return JDSP_OK;
     }
     return fail(ctx, JDSP_EINVAL, "jdsp_set_option: unknown option");
@@ -338,19 +345,28 @@ int jdsp_stft_i16_dev(jdsp_ctx *ctx, const int16_t *pcm_dev, long n_frames, int 
     JDSP_HIP(ctx, hipSetDevice(ctx->device));
     int rc = jdsp::ensure_stft1024_table(ctx);
     if (rc) return rc;
+    const int wk = ctx->opt_stft_window;
+    if (wk == 1 && !ctx->stft1024_table_hann) {          // same tables, Hann in the window slots
+        const int n = jdsp::stft1024_table_count();
+        std::vector<float2> host((size_t)n);
+        jdsp::fill_stft1024_table(host.data(), 1);
+        JDSP_HIP(ctx, hipMalloc((void **)&ctx->stft1024_table_hann, sizeof(float2) * (size_t)n));
+        JDSP_HIP(ctx, hipMemcpy(ctx->stft1024_table_hann, host.data(), sizeof(float2) * (size_t)n, hipMemcpyHostToDevice));
+    }
+    const float2 *tab = wk == 1 ? ctx->stft1024_table_hann : ctx->stft1024_table;
     if (n_fft == 512) {
-        if (!ctx->win512) {
+        float2 *&w512 = wk == 1 ? ctx->win512_hann : ctx->win512;
+        if (!w512) {
             float2 w[256];
-            jdsp::fill_win512(w);
-            JDSP_HIP(ctx, hipMalloc((void **)&ctx->win512, sizeof(w)));
-            JDSP_HIP(ctx, hipMemcpy(ctx->win512, w, sizeof(w), hipMemcpyHostToDevice));
+            jdsp::fill_win512(w, wk);
+            JDSP_HIP(ctx, hipMalloc((void **)&w512, sizeof(w)));
+            JDSP_HIP(ctx, hipMemcpy(w512, w, sizeof(w), hipMemcpyHostToDevice));
         }
-        if (jdsp::launch_stft512(ctx->stream, ctx->n_cu, pcm_dev, n_frames, hop, (float2 *)spec_dev, ctx->stft1024_table,
-                                 ctx->win512))
+        if (jdsp::launch_stft512(ctx->stream, ctx->n_cu, pcm_dev, n_frames, hop, (float2 *)spec_dev, tab, w512))
             return fail(ctx, JDSP_EHIP, "stft512 launch", hipGetLastError());
         return JDSP_OK;
     }
-    if (jdsp::launch_stft1024(ctx->stream, ctx->n_cu, ctx->opt_stft_fpw, pcm_dev, n_frames, hop, (float2 *)spec_dev, ctx->stft1024_table))
+    if (jdsp::launch_stft1024(ctx->stream, ctx->n_cu, ctx->opt_stft_fpw, pcm_dev, n_frames, hop, (float2 *)spec_dev, tab))
         return fail(ctx, JDSP_EHIP, "stft1024 launch", hipGetLastError());
     return JDSP_OK;
 }

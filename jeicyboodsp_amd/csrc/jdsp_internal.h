@@ -20,6 +20,8 @@ struct jdsp_ctx {
     hipStream_t stream = nullptr;      // the stream work is enqueued on
     std::string error;
     int opt_stft_fpw = 0;              // 0 = auto
+    int opt_stft_window = 0;           // 0 Hamming (the reference), 1 Hann -- jdsp_stft_* only
+    float2 *stft1024_table_hann = nullptr, *win512_hann = nullptr;
     // device tables, created on first use
     float2 *stft1024_table = nullptr;
     float2 *win512 = nullptr;          // halved Hamming-512 pairs
@@ -84,14 +86,14 @@ int fail(jdsp_ctx *ctx, int code, const char *what, hipError_t e = hipSuccess);
 
 // stft_kernels.hip
 int stft1024_table_count();
-void fill_stft1024_table(float2 *host_table);
+void fill_stft1024_table(float2 *host_table, int window_kind);
 int launch_stft1024(hipStream_t stream, int n_cu, int fpw_opt, const short *pcm, long n_frames, long hop, float2 *spec,
                     const float2 *table);
 
 
 int launch_stft512(hipStream_t stream, int n_cu, const short *pcm, long n_frames, long hop, float2 *spec,
                    const float2 *table, const float2 *win512);
-void fill_win512(float2 *w);
+void fill_win512(float2 *w, int window_kind);
 
 // fft_c2c_kernels.hip
 int launch_bitrev_table(hipStream_t stream, short *table_dev, int n_fft, int bits);

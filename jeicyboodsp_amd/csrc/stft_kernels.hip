@@ -247,11 +247,12 @@ int launch_stft512(hipStream_t stream, int n_cu, const short *pcm, long n_frames
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
-void fill_win512(float2 *w)
+void fill_win512(float2 *w, int window_kind)
 {
+    const double wa = window_kind == 1 ? 0.5 : 0.54, wb = window_kind == 1 ? 0.5 : 0.46;
     for (int i = 0; i < 256; i++) {
-        const double w0 = (0.54 - 0.46 * cos(2 * 3.141592 * (2 * i) / (512 - 1)));
-        const double w1 = (0.54 - 0.46 * cos(2 * 3.141592 * (2 * i + 1) / (512 - 1)));
+        const double w0 = (wa - wb * cos(2 * 3.141592 * (2 * i) / (512 - 1)));
+        const double w1 = (wa - wb * cos(2 * 3.141592 * (2 * i + 1) / (512 - 1)));
         w[i] = make_float2((float)(0.5 * w0), (float)(0.5 * w1));
     }
 }
@@ -293,8 +294,10 @@ int launch_stft1024(hipStream_t stream, int n_cu, int fpw_opt, const short *pcm,
 int stft1024_table_count() { return kStftTableCount; }
 
 // Host-side table contents (double precision, rounded once to float).
-void fill_stft1024_table(float2 *t)
+void fill_stft1024_table(float2 *t, int window_kind)
 {
+    // window_kind 0: the reference's Hamming 0.54 - 0.46 cos; 1: Hann 0.5 - 0.5 cos (same argument)
+    const double wa = window_kind == 1 ? 0.5 : 0.54, wb = window_kind == 1 ? 0.5 : 0.46;
     const double two_pi = 6.283185307179586476925286766559;
     for (int k = 1; k < 8; k++)
         for (int l = 0; l < 64; l++) {
@@ -308,8 +311,8 @@ void fill_stft1024_table(float2 *t)
         }
     // Hamming exactly as the reference writes it (PI 3.141592, SS:52,226); halved copy for the split
     for (int i = 0; i < 512; i++) {
-        double w0 = (0.54 - 0.46 * cos(2 * 3.141592 * (2 * i) / (1024 - 1)));
-        double w1 = (0.54 - 0.46 * cos(2 * 3.141592 * (2 * i + 1) / (1024 - 1)));
+        double w0 = (wa - wb * cos(2 * 3.141592 * (2 * i) / (1024 - 1)));
+        double w1 = (wa - wb * cos(2 * 3.141592 * (2 * i + 1) / (1024 - 1)));
         t[kStftWin + i] = make_float2((float)(0.5 * w0), (float)(0.5 * w1));
         t[kStftWinFull + i] = make_float2((float)w0, (float)w1);
     }

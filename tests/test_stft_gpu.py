@@ -129,3 +129,24 @@ def test_stft_pinned_host_buffers_take_the_pipelined_path(eng, oracle):
     idx = np.r_[0:8, 4090:4100, 8190:8200, n_frames - 8:n_frames]
     want = np.stack([oracle.stft(pcm[512 * f:512 * f + 1024], 1)[0] for f in idx])
     _check(got[idx].astype(np.complex128), want)
+
+
+@pytest.mark.parametrize("n_fft,hop", [(1024, 512), (512, 256)])
+def test_stft_hann_window_option(eng, n_fft, hop):
+    """north_star names Hann next to Hamming; the reference only has Hamming, so this one is checked
+    against numpy's FFT of the Hann-windowed frames (same 0.5-0.5cos(2*3.141592*i/(n-1)) form)."""
+    n_frames = 40
+    pcm = _pcm(21, hop * (n_frames - 1) + n_fft)
+    eng.set_option("stft.window", 1)
+    try:
+        got = eng.stft(pcm, n_fft=n_fft, hop=hop).astype(np.complex128)
+    finally:
+        eng.set_option("stft.window", 0)
+    i = np.arange(n_fft)
+    w = 0.5 - 0.5 * np.cos(2 * 3.141592 * i / (n_fft - 1))
+    frames = np.lib.stride_tricks.sliding_window_view(pcm, n_fft)[::hop][:n_frames].astype(np.float64)
+    _check(got, np.fft.fft(frames * w, axis=1))
+    # and the default is back to the reference's Hamming
+    ham = eng.stft(pcm, n_fft=n_fft, hop=hop).astype(np.complex128)
+    wh = 0.54 - 0.46 * np.cos(2 * 3.141592 * i / (n_fft - 1))
+    _check(ham, np.fft.fft(frames * wh, axis=1))
