@@ -20,7 +20,7 @@ __device__ __forceinline__ short bitrev16(int k, int bits, int n_fft)
     short rev = walk;
     for (int i = 1; i < bits; i++) {
         walk = (short)(walk >> 1);
-        rev = (short)(rev << 1);
+        rev = (short)(unsigned short)(((unsigned)(unsigned short)rev) << 1);    // <<= 1 on the 16-bit pattern
         rev = (short)(rev | (walk & 1));
     }
     return (short)(rev & (n_fft - 1));

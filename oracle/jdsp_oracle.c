@@ -44,7 +44,9 @@ void orc_bitrev_table(int n_fft, int block_len, short *table)
         short rev = walk;        /* :193 */
         for (int i = 1; i < bits; i++) {          /* :195-200, all in 16-bit */
             walk = (short)(walk >> 1);
-            rev = (short)(rev << 1);
+            /* psBit[k] <<= 1 on a short: done on the unsigned 16-bit pattern (a negative left
+             * operand is undefined in C; every compiler the reference met wraps) */
+            rev = (short)(unsigned short)(((unsigned)(unsigned short)rev) << 1);
             rev = (short)(rev | (walk & 1));
         }
         table[k] = (short)(rev & (n_fft - 1));    /* :202 */
