@@ -104,6 +104,11 @@ int jdsp_fft_process_f64_dev(jdsp_ctx *ctx, const double *in_dev, double *out_de
  * 1024-point transform). */
 int jdsp_stft_i16_dev(jdsp_ctx *ctx, const int16_t *pcm_dev, long n_frames,
                       int n_fft, int hop, jdsp_c32 *spec_dev);
+/* Half-spectrum variant (n_fft 1024, hop 512, Hamming): bins 0..512 only, row f at
+ * spec_dev + f * row_pitch complex64 (row_pitch >= 513; 513 = dense rows of 4,104 B instead of
+ * 8,192).  The reference keeps all 1024 bins, so this is an extra, measured separately
+ * (5,128 algorithmic bytes per frame). */
+int jdsp_stft_half_i16_dev(jdsp_ctx *ctx, const int16_t *pcm_dev, long n_frames, jdsp_c32 *spec_dev, long row_pitch);
 int jdsp_stft_i16(jdsp_ctx *ctx, const int16_t *pcm_host, long n_samples,
                   int n_fft, int hop, jdsp_c32 *spec_host, long *n_frames_out);
 

@@ -109,6 +109,7 @@ def _load():
         "jdsp_mvdrn_blocks_out": (l, [vp, l]),
         "jdsp_mvdrn_process_dev": (i, [vp, vp, l, l, vp, vp, C.POINTER(l)]),
         "jdsp_mvdrn_process": (i, [vp, vp, l, l, vp, vp, C.POINTER(l)]),
+        "jdsp_stft_half_i16_dev": (i, [vp, vp, l, vp, l]),
         "jdsp_stft_i16_dev": (i, [vp, vp, l, i, i, vp]),
         "jdsp_stft_i16": (i, [vp, vp, l, i, i, vp, C.POINTER(l)]),
     }

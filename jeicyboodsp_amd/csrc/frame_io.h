@@ -36,29 +36,28 @@ __device__ __forceinline__ unsigned int cast_i16_bits(float v)
 template <int J>
 __device__ __forceinline__ void split_fwd(float2 zm, float2 zr, float2 wsp, float2 &lo, float2 &hi)
 {
-    const float2 e = make_float2(zm.x + zr.x, zm.y - zr.y);
-    const float2 o = make_float2(zm.y + zr.y, zr.x - zm.x);
-    float2 t = cmul(wsp, o);
-    if (J == 1) t = rot45<false>(t);
-    if (J == 2) t = rot90<false>(t);
-    if (J == 3) t = rot135<false>(t);
-    lo = cadd(e, t);
-    hi = csub(e, t);
+    const float2 e = cadd_conj(zm, zr);
+    const float2 o = csub_conj_mj(zm, zr);
+    const float2 t = cmul(wsp, o);
+    if (J == 0) { lo = cadd(e, t); hi = csub(e, t); }
+    if (J == 1) { const float2 p = one_rot<false>(t); lo = cfma(p, inv_sqrt2_pair(), e); hi = cfnma(p, inv_sqrt2_pair(), e); }
+    if (J == 2) { lo = cadd_mj(e, t); hi = cadd_pj(e, t); }
+    if (J == 3) { const float2 p = one_rot<true>(t); lo = cfnma(p, inv_sqrt2_pair(), e); hi = cfma(p, inv_sqrt2_pair(), e); }
 }
 
 // Inverse pre-split: from Y[m] and Y[m+512] of a Hermitian spectrum,
 // Z'[m] = (Y[m] + Y[m+512]) + j (Y[m] - Y[m+512]) conj(W^m); then
-// y[2n] + j y[2n+1] = IDFT512_unnormalised(Z')[n] / 1024.
+// y[2n] + j y[2n+1] = IDFT512_unnormalised(Z')[n] / 1024.  With r = (Y[m] - Y[m+512]) conj(wsp) and
+// conj(w_8^J) = 1, (1+j)/sqrt2, j, (-1+j)/sqrt2:  Z' = s + j r,  s - (1-j) r/sqrt2,  s - r,  s - (1+j) r/sqrt2.
 template <int J>
 __device__ __forceinline__ float2 presplit_inv(float2 ylo, float2 yhi, float2 wsp)
 {
     const float2 s = cadd(ylo, yhi);
-    float2 d = csub(ylo, yhi);
-    if (J == 1) d = rot45<true>(d);
-    if (J == 2) d = rot90<true>(d);
-    if (J == 3) d = rot135<true>(d);
-    d = cmul_conj(d, wsp);
-    return make_float2(s.x - d.y, s.y + d.x);     // s + j d
+    const float2 r = cmul_conj(csub(ylo, yhi), wsp);
+    if (J == 0) return cadd_pj(s, r);
+    if (J == 1) return cfnma(one_rot<false>(r), inv_sqrt2_pair(), s);
+    if (J == 2) return csub(s, r);
+    return cfnma(one_rot<true>(r), inv_sqrt2_pair(), s);
 }
 
 struct FrameTables {

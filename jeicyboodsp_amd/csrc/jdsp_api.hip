@@ -371,6 +371,22 @@ int jdsp_stft_i16_dev(jdsp_ctx *ctx, const int16_t *pcm_dev, long n_frames, int 
     return JDSP_OK;
 }
 
+int jdsp_stft_half_i16_dev(jdsp_ctx *ctx, const int16_t *pcm_dev, long n_frames, jdsp_c32 *spec_dev, long row_pitch)
+{
+    if (!ctx) return JDSP_EINVAL;
+    if (n_frames < 0 || (n_frames > 0 && (!pcm_dev || !spec_dev))) return fail(ctx, JDSP_EINVAL, "jdsp_stft_half_i16_dev: bad buffer");
+    if (row_pitch < 513) return fail(ctx, JDSP_EINVAL, "jdsp_stft_half_i16_dev: row_pitch must be at least 513");
+    if (n_frames == 0) return JDSP_OK;
+    if (((uintptr_t)pcm_dev & 15u) || ((uintptr_t)spec_dev & 15u))
+        return fail(ctx, JDSP_EINVAL, "jdsp_stft_half_i16_dev: buffers must be 16-byte aligned");
+    JDSP_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = jdsp::ensure_stft1024_table(ctx);
+    if (rc) return rc;
+    if (jdsp::launch_stft1024_half(ctx->stream, pcm_dev, n_frames, (float2 *)spec_dev, row_pitch, ctx->stft1024_table))
+        return fail(ctx, JDSP_EHIP, "stft half launch", hipGetLastError());
+    return JDSP_OK;
+}
+
 static bool is_pinned_host(const void *p)
 {
     hipPointerAttribute_t a;

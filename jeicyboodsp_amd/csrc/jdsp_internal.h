@@ -91,6 +91,8 @@ int launch_stft1024(hipStream_t stream, int n_cu, int fpw_opt, const short *pcm,
                     const float2 *table);
 
 
+int launch_stft1024_half(hipStream_t stream, const short *pcm, long n_frames, float2 *spec, long pitch,
+                         const float2 *table);
 int launch_stft512(hipStream_t stream, int n_cu, const short *pcm, long n_frames, long hop, float2 *spec,
                    const float2 *table, const float2 *win512);
 void fill_win512(float2 *w, int window_kind);

@@ -153,6 +153,110 @@ __global__ __launch_bounds__(64, JDSP_STFT_MINWAVES) void stft1024_hop512_kernel
     }
 }
 
+// ---- half spectrum: bins 0..512 only (the other 511 are their conjugates) -------------------------
+// [frame][513] complex64, 4,104 B per frame, so odd rows start 8 bytes off a 16-byte boundary.  Every
+// store is still a full aligned 16 bytes: on even rows a lane writes the bins (m, m+1), m = 128 j + 2 lane,
+// and bin 512 goes out alone; on odd rows it writes (m+1, m+2) -- the last pair is (511, 512) -- and
+// bin 0 goes out alone.  (8-byte stores at a 16-byte stride turn every line into partial writes and cost
+// the whole saving.)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <int J, bool ODD>
+__device__ __forceinline__ void split_store_half_j(const float2 *lds, int lane, const float2 *w2, float2 *row)
+{
+    const int m = 128 * J + 2 * lane + (ODD ? 1 : 0);            // first bin of this lane's pair
+    float2 z0, z1;
+    if (ODD) { z0 = lds[m]; z1 = lds[(m + 1) & 511]; }
+    else { const float4 zz = *reinterpret_cast<const float4 *>(&lds[m]); z0 = make_float2(zz.x, zz.y); z1 = make_float2(zz.z, zz.w); }
+    const float2 zr0 = lds[(512 - m) & 511];
+    const float2 zr1 = lds[511 - m];
+    float2 lo0, hi0, lo1, hi1;
+    split_fwd<J>(z0, zr0, w2[0], lo0, hi0);                      // W^m = w_8^J * W^(m - 128 J); m = 512 gives -1
+    split_fwd<J>(z1, zr1, w2[1], lo1, hi1);
+    f32x4 t = {lo0.x, lo0.y, lo1.x, lo1.y};
+    __builtin_nontemporal_store(t, reinterpret_cast<f32x4 *>(row + m));
+    if (J == 0 && lane == 0) {
+        if (ODD) {                                               // bin 0: E + O of Z[0] with itself
+            const float2 z = lds[0];
+            float2 l, h;
+            split_fwd<0>(z, z, make_float2(1.f, 0.f), l, h);
+            f32x2 n = {l.x, l.y};
+            __builtin_nontemporal_store(n, reinterpret_cast<f32x2 *>(row));
+        } else {                                                 // bin 512 = X[0 + 512]
+            f32x2 n = {hi0.x, hi0.y};
+            __builtin_nontemporal_store(n, reinterpret_cast<f32x2 *>(row + 512));
+        }
+    }
+}
+
+template <bool ODD>
+__device__ __forceinline__ void split_store_half(const float2 *lds, int lane, const float2 *w2, float2 *row)
+{
+    split_store_half_j<0, ODD>(lds, lane, w2, row);
+    split_store_half_j<1, ODD>(lds, lane, w2, row);
+    split_store_half_j<2, ODD>(lds, lane, w2, row);
+    split_store_half_j<3, ODD>(lds, lane, w2, row);
+}
+
+template <int K>
+__global__ __launch_bounds__(64, JDSP_STFT_MINWAVES) void stft1024_hop512_half_kernel(
+    const short *__restrict__ pcm, float2 *__restrict__ spec, long n_frames, long pitch,
+    const float2 *__restrict__ table)
+{
+    __shared__ __attribute__((aligned(16))) float2 lds[kWaveLdsComplex];
+    __shared__ __attribute__((aligned(16))) unsigned int stage[256];
+    const int lane = threadIdx.x;
+    const long per_xcd = (gridDim.x + 7) >> 3;
+    const long f0 = ((long)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3)) * K;
+    if (f0 >= n_frames) return;
+    const u32x4 *pcm128 = reinterpret_cast<const u32x4 *>(pcm) + lane;
+    u32x4 half[K + 1];
+#pragma unroll
+    for (int h = 0; h <= K; h++) half[h] = pcm128[(f0 + h <= n_frames ? f0 + h : n_frames) * 64];
+    FrameTables t;
+    load_frame_tables(t, table, lane);
+    static_assert(K % 2 == 0, "row parity is taken from the in-wave frame index");
+    const float2 wsp2 = table[kStftSplit + 2 * lane + 2];        // W^(2 lane + 2); lane 63: W^128
+    unsigned int raw[8];
+    relayout_half(stage, lane, half[0], raw + 4);
+#pragma unroll
+    for (int i = 0; i < K; i++) {
+        const long f = f0 + i;
+        if (f >= n_frames) break;
+        float2 v[8];
+#pragma unroll
+        for (int r = 0; r < 4; r++) raw[r] = raw[r + 4];
+        relayout_half(stage, lane, half[i + 1], raw + 4);
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const float2 s = unpack_i16x2(raw[r]);
+            v[r] = make_float2(s.x * t.win[r].x, s.y * t.win[r].y);
+        }
+        wave_fft512<false>(v, lds, lane, t.tw);
+#pragma unroll
+        for (int d = 0; d < 8; d++) lds[lane + 64 * d] = v[d];
+        wave_lds_fence();
+        float2 *row = spec + f * pitch;
+        if ((i & 1) && (pitch & 1)) {                            // f0 is even (K is): odd row of an odd pitch
+            const float2 wodd[2] = {t.wsp[1], wsp2};
+            split_store_half<true>(lds, lane, wodd, row);
+        } else {
+            split_store_half<false>(lds, lane, t.wsp, row);
+        }
+        wave_lds_fence();
+    }
+}
+
+int launch_stft1024_half(hipStream_t stream, const short *pcm, long n_frames, float2 *spec, long pitch,
+                         const float2 *table)
+{
+    if (n_frames <= 0) return 0;
+    const long grid = ((n_frames + 1) / 2 + 7) / 8 * 8;
+    hipLaunchKernelGGL(stft1024_hop512_half_kernel<2>, dim3((unsigned)grid), dim3(64), 0, stream, pcm, spec, n_frames,
+                       pitch, table);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 // any hop: every frame fetches its own 1024 samples with 16-bit loads.
 __global__ __launch_bounds__(64) void stft1024_anyhop_kernel(const short *__restrict__ pcm, float2 *__restrict__ spec,
                                                              long n_frames, int frames_per_wave, long hop,

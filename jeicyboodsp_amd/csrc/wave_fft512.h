@@ -23,49 +23,97 @@ namespace jdsp {
 constexpr int kWaveLdsComplex = 8 * 73;          // 584 complex = 4672 B per wave
 constexpr float kInvSqrt2 = 0.70710678118654752440f;
 
-__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
-__device__ __forceinline__ float2 cmul(float2 a, float2 b)
+// ---- packed complex arithmetic ---------------------------------------------------------------------
+// A complex number is one even-aligned VGPR pair (re, im); gfx950's VOP3P packed-FP32 instructions
+// take, per source and per result half, a half selection (op_sel / op_sel_hi) and a negation
+// (neg_lo / neg_hi).  That makes a + b, a - b, a +- j b and (1 +- j) a ONE v_pk_add_f32, a complex
+// product v_pk_mul_f32 + v_pk_fma_f32, and the 1/sqrt2 of the odd eighth roots foldable into a
+// v_pk_fma_f32.  The compiler does not form the mixed per-half selections (it falls back to two FMAs
+// plus v_mov/v_pk_mov per product: 370 VALU instructions per frame against 205 spelled out), and at 4
+// issue cycles per wave64 instruction the transform is VALU-issue-bound, so they are spelled out.
+typedef float cfv __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ cfv tv(float2 a) { cfv r = {a.x, a.y}; return r; }
+__device__ __forceinline__ float2 fv(cfv r) { return make_float2(r.x, r.y); }
+
+#define JDSP_PK_ADD(NAME, MODS)                                                                     \
+    __device__ __forceinline__ float2 NAME(float2 a, float2 b)                                     \
+    {                                                                                               \
+        cfv r;                                                                                      \
+        asm("v_pk_add_f32 %0, %1, %2 " MODS : "=v"(r) : "v"(tv(a)), "v"(tv(b)));                   \
+        return fv(r);                                                                               \
+    }
+JDSP_PK_ADD(cadd, "")                                                     // a + b
+JDSP_PK_ADD(csub, "neg_lo:[0,1] neg_hi:[0,1]")                            // a - b
+JDSP_PK_ADD(cadd_mj, "op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]")         // a - j b = (a.x + b.y, a.y - b.x)
+JDSP_PK_ADD(cadd_pj, "op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]")         // a + j b = (a.x - b.y, a.y + b.x)
+JDSP_PK_ADD(cadd_conj, "neg_hi:[0,1]")                                    // a + conj(b)
+JDSP_PK_ADD(csub_conj_mj, "op_sel:[1,1] op_sel_hi:[0,0] neg_hi:[1,0]")    // -j (a - conj(b)) = (a.y + b.y, b.x - a.x)
+#undef JDSP_PK_ADD
+
+// d = c + s * a  /  c - s * a  with a real scale s held in both halves of `s2`, and the same with a
+// rotated by -j or +j first
+#define JDSP_PK_FMA(NAME, MODS)                                                                     \
+    __device__ __forceinline__ float2 NAME(float2 a, cfv s2, float2 c)                             \
+    {                                                                                               \
+        cfv r;                                                                                      \
+        asm("v_pk_fma_f32 %0, %1, %2, %3 " MODS : "=v"(r) : "v"(tv(a)), "v"(s2), "v"(tv(c)));      \
+        return fv(r);                                                                               \
+    }
+JDSP_PK_FMA(cfma, "")                                                                   // c + s a
+JDSP_PK_FMA(cfnma, "neg_lo:[1,0,0] neg_hi:[1,0,0]")                                     // c - s a
+JDSP_PK_FMA(cfma_mj, "op_sel:[1,0,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]")                 // c + s (-j a)
+JDSP_PK_FMA(cfma_pj, "op_sel:[1,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]")                 // c + s (+j a)
+#undef JDSP_PK_FMA
+
+__device__ __forceinline__ cfv inv_sqrt2_pair() { cfv c = {kInvSqrt2, kInvSqrt2}; return c; }
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 w)             // a * w
 {
-    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+    cfv t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,1] neg_lo:[1,0]" : "=v"(t) : "v"(tv(a)), "v"(tv(w)));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(r) : "v"(tv(a)), "v"(tv(w)), "v"(t));
+    return fv(r);
 }
-__device__ __forceinline__ float2 cmul_conj(float2 a, float2 b)   // a * conj(b)
+__device__ __forceinline__ float2 cmul_conj(float2 a, float2 w)        // a * conj(w)
 {
-    return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
+    cfv t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,1] neg_hi:[1,0]" : "=v"(t) : "v"(tv(a)), "v"(tv(w)));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(r) : "v"(tv(a)), "v"(tv(w)), "v"(t));
+    return fv(r);
 }
+// a + rot(b), a - rot(b) with rot = multiplication by -j (forward) or +j (inverse)
+template <bool INV> __device__ __forceinline__ float2 cadd_rot90(float2 a, float2 b) { return INV ? cadd_pj(a, b) : cadd_mj(a, b); }
+template <bool INV> __device__ __forceinline__ float2 csub_rot90(float2 a, float2 b) { return INV ? cadd_mj(a, b) : cadd_pj(a, b); }
+// (1 - j) a (forward) or (1 + j) a (inverse): sqrt2 * w_8^1 a
+template <bool INV> __device__ __forceinline__ float2 one_rot(float2 a) { return INV ? cadd_pj(a, a) : cadd_mj(a, a); }
+
 // multiply by -j (forward) or +j (inverse)
 template <bool INV> __device__ __forceinline__ float2 rot90(float2 a)
 {
     return INV ? make_float2(-a.y, a.x) : make_float2(a.y, -a.x);
 }
-// multiply by w_8^1 = (1-j)/sqrt2 (forward) or its conjugate (inverse)
-template <bool INV> __device__ __forceinline__ float2 rot45(float2 a)
-{
-    return INV ? make_float2(kInvSqrt2 * (a.x - a.y), kInvSqrt2 * (a.x + a.y))
-               : make_float2(kInvSqrt2 * (a.x + a.y), kInvSqrt2 * (a.y - a.x));
-}
-// multiply by w_8^3 = (-1-j)/sqrt2 (forward) or its conjugate (inverse)
-template <bool INV> __device__ __forceinline__ float2 rot135(float2 a)
-{
-    return INV ? make_float2(-kInvSqrt2 * (a.x + a.y), kInvSqrt2 * (a.x - a.y))
-               : make_float2(kInvSqrt2 * (a.y - a.x), -kInvSqrt2 * (a.x + a.y));
-}
 
-// In-register 8-point DFT, natural order in and out.
+// In-register 8-point DFT, natural order in and out: 26 packed instructions.  The odd eighth roots
+// w_8 = (1 -+ j)/sqrt2 and w_8^3 = -(1 +- j)/sqrt2 enter as p5 = (1 -+ j) d1 and p7 = (1 +- j) d3 with
+// the 1/sqrt2 folded into the last stage's FMAs: w_8 d1 + w_8^3 d3 = (p5 - p7)/sqrt2 and
+// w_8 d1 - w_8^3 d3 = (p5 + p7)/sqrt2.
 template <bool INV> __device__ __forceinline__ void dft8(float2 (&v)[8])
 {
-    float2 a0 = cadd(v[0], v[4]), a4 = csub(v[0], v[4]);
-    float2 a1 = cadd(v[1], v[5]), a5 = rot45<INV>(csub(v[1], v[5]));
-    float2 a2 = cadd(v[2], v[6]), a6 = rot90<INV>(csub(v[2], v[6]));
-    float2 a3 = cadd(v[3], v[7]), a7 = rot135<INV>(csub(v[3], v[7]));
-    float2 b0 = cadd(a0, a2), b2 = csub(a0, a2);
-    float2 b1 = cadd(a1, a3), b3 = rot90<INV>(csub(a1, a3));
-    float2 b4 = cadd(a4, a6), b6 = csub(a4, a6);
-    float2 b5 = cadd(a5, a7), b7 = rot90<INV>(csub(a5, a7));
+    const cfv c = inv_sqrt2_pair();
+    const float2 a0 = cadd(v[0], v[4]), a4 = csub(v[0], v[4]);
+    const float2 a1 = cadd(v[1], v[5]), d1 = csub(v[1], v[5]);
+    const float2 a2 = cadd(v[2], v[6]), d2 = csub(v[2], v[6]);
+    const float2 a3 = cadd(v[3], v[7]), d3 = csub(v[3], v[7]);
+    const float2 p5 = one_rot<INV>(d1), p7 = one_rot<!INV>(d3);
+    const float2 b0 = cadd(a0, a2), b2 = csub(a0, a2);
+    const float2 b1 = cadd(a1, a3), d13 = csub(a1, a3);
+    const float2 b4 = cadd_rot90<INV>(a4, d2), b6 = csub_rot90<INV>(a4, d2);
+    const float2 u = csub(p5, p7), w = cadd(p5, p7);
     v[0] = cadd(b0, b1); v[4] = csub(b0, b1);
-    v[2] = cadd(b2, b3); v[6] = csub(b2, b3);
-    v[1] = cadd(b4, b5); v[5] = csub(b4, b5);
-    v[3] = cadd(b6, b7); v[7] = csub(b6, b7);
+    v[2] = cadd_rot90<INV>(b2, d13); v[6] = csub_rot90<INV>(b2, d13);
+    v[1] = cfma(u, c, b4); v[5] = cfnma(u, c, b4);
+    v[3] = INV ? cfma_pj(w, c, b6) : cfma_mj(w, c, b6);
+    v[7] = INV ? cfma_mj(w, c, b6) : cfma_pj(w, c, b6);
 }
 
 // Orders this wave's LDS traffic for the compiler without any hardware wait:

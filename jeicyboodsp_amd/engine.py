@@ -129,6 +129,20 @@ class Engine:
                                        ac.ctypes.data_as(C.c_void_p) if want_autocorr else None))
         return (arg, rmax, ac) if want_autocorr else (arg, rmax)
 
+    def stft_half(self, pcm, n_frames=None, out=None, pitch=513):
+        """Bins 0..512 only: complex64 [n_frames, pitch >= 513], columns past 512 untouched."""
+        import torch
+        assert pcm.is_cuda and pcm.dtype == torch.int16 and pcm.is_contiguous()
+        if n_frames is None:
+            n_frames = (pcm.numel() - 1024) // 512 + 1 if pcm.numel() >= 1024 else 0
+        if out is None:
+            out = torch.empty((n_frames, pitch), dtype=torch.complex64, device=pcm.device)
+        assert out.is_contiguous() and out.shape[-1] == pitch
+        self._use_torch_stream()
+        self._ck(L.jdsp_stft_half_i16_dev(self._h, C.c_void_p(pcm.data_ptr()), n_frames, C.c_void_p(out.data_ptr()),
+                                          pitch))
+        return out
+
     # ---- STFT analysis (SS:218-230 / WF:181-193 for a whole batch) ---------
     def stft(self, pcm, n_frames=None, n_fft=1024, hop=512, out=None):
         """pcm: int16 numpy array (host path) or torch CUDA int16 tensor (device path).

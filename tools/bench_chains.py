@@ -83,6 +83,13 @@ def main():
     def on(n):
         return want is None or n in want
 
+    if on("stft_half"):
+        x = torch.from_numpy(pcm_of(rng, 512 * (B + 1))).cuda()
+        for pitch in (513, 514, 516, 520, 528, 576, 1024):
+            hs = torch.empty((B, pitch), dtype=torch.complex64, device="cuda")
+            ms = timed(lambda: eng.stft_half(x, B, out=hs, pitch=pitch), a.iters)
+            report(f"stft_half_spectrum_513_bins_pitch{pitch}", ms, B, "frames", 1024 + 4104, 5 * 512 * 9 + 512 * 14,
+                   "extra: bins 0..512 only (5,128 algorithmic bytes per frame); the headline keeps all 1024 bins")
     if on("denoise"):
         x = pcm_of(rng, B * 512)
         x[:12 * 512] = pcm_of(rng, 12 * 512, 45.0)          # the estimate latches at block 10
