@@ -299,6 +299,57 @@ int jdsp_mfcc_frames_dev(jdsp_mfcc *h, const int16_t *pcm_dev, const int64_t *fr
 int jdsp_mfcc_frames(jdsp_mfcc *h, const int16_t *pcm_host, long n_samples, const int64_t *frame_start_host,
                      long n_frames, double *feats_host);
 
+/* ---- GMM scoring / HMM recursion on MFCC vectors ------------- */
+/* GMMAlgorithm_Test_Auto_ver2.cpp and Viterbi_version1.cpp consume the 12-double vectors the MFCC program
+ * writes (MFCC:99); here they are read where jdsp_mfcc_frames_dev left them, in HBM.  The parameter records
+ * are the programs' own (GMMTest:29-34; Viterbi:30-40), byte for byte, so a parameter file (GMMTest:76,
+ * Viterbi:80) can be read straight into an array of them.  Everything is FP64 like the reference.
+ * A batch is a set of utterances: utterance u owns the vectors utt_first[u] .. utt_first[u+1]-1
+ * (n_utts + 1 offsets, non-decreasing). */
+typedef struct {
+    double alpa[4];
+    double mean[4][12];
+    double covariance[4][12][12];
+    double eigenVector[4][12][4];
+} jdsp_gmm_param;
+typedef struct {
+    jdsp_gmm_param gMMParam[6];
+    double transProb[6][6];
+} jdsp_hmm_param;
+
+typedef struct jdsp_gmm jdsp_gmm;
+/* classes: n_classes (1..256) records; what probability() reads of them (GMMTest:216-235) is packed and
+ * uploaded: eigenVector, mean[k][0..3], covariance[k][i][i] for i < 4. */
+int jdsp_gmm_create(jdsp_ctx *ctx, const jdsp_gmm_param *classes, int n_classes, jdsp_gmm **out);
+int jdsp_gmm_destroy(jdsp_gmm *h);
+/* Recognition() (GMMTest:151-162) of every utterance against every class and main()'s arg-max
+ * (GMMTest:113-127: `dMax < score`, first maximum wins).  scores: [n_utts][n_classes] doubles,
+ * best (may be NULL): [n_utts] 0-based class indices.  feats: n_frames vectors, 16-byte aligned; offsets
+ * outside [0, n_frames] are clamped on the device (nothing outside feats is ever read).  The host entry takes
+ * n_frames from utt_first_host[n_utts] and requires utt_first_host[0] == 0. */
+int jdsp_gmm_score_dev(jdsp_gmm *h, const double *feats_dev, long n_frames, const int64_t *utt_first_dev,
+                       long n_utts, double *scores_dev, int *best_dev);
+int jdsp_gmm_score(jdsp_gmm *h, const double *feats_host, const int64_t *utt_first_host, long n_utts,
+                   double *scores_host, int *best_host);
+
+typedef struct jdsp_hmm jdsp_hmm;
+/* models: n_models (1..1024) six-state records; log(transProb) is taken here, on the host (Viterbi:196). */
+int jdsp_hmm_create(jdsp_ctx *ctx, const jdsp_hmm_param *models, int n_models, jdsp_hmm **out);
+int jdsp_hmm_destroy(jdsp_hmm *h);
+/* Sizes the emission scratch (n_frames * n_models * 6 doubles) ahead of time, e.g. before a graph capture. */
+int jdsp_hmm_reserve(jdsp_hmm *h, long n_frames);
+/* HMMRecognition() (Viterbi:157-246) as the reference computes it, quirks included (see
+ * oracle/jdsp_oracle.h: log of the accumulated log probability at :196; the "decoding result" is the
+ * per-frame arg-max state; the returned value is the frame-1 maximum).  n_frames = total vectors; every
+ * utt_first offset must lie in [0, n_frames].  scores (may be NULL): [n_utts][n_models]; best (may be NULL):
+ * [n_utts] arg-max model (Viterbi:119-126); path (may be NULL): [n_models][n_frames] states, 0 at each
+ * utterance's first frame; trellis (may be NULL): [n_models][6][n_frames] = sProb.dHMMProb. */
+int jdsp_hmm_viterbi_dev(jdsp_hmm *h, const double *feats_dev, long n_frames, const int64_t *utt_first_dev,
+                         long n_utts, double *scores_dev, int *best_dev, int *path_dev, double *trellis_dev);
+/* host entry: utt_first_host[0] must be 0 and utt_first_host[n_utts] is the total number of vectors */
+int jdsp_hmm_viterbi(jdsp_hmm *h, const double *feats_host, const int64_t *utt_first_host, long n_utts,
+                     double *scores_host, int *best_host, int *path_host);
+
 #ifdef __cplusplus
 }
 #endif

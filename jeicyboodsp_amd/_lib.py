@@ -68,6 +68,15 @@ def _load():
         "jdsp_denoise_process": (i, [vp, vp, l, vp, vp, C.POINTER(l)]),
         "jdsp_denoise_noise": (i, [vp, vp]),
         "jdsp_denoise_vad_trace": (i, [vp, l, vp, vp, vp]),
+        "jdsp_gmm_create": (i, [vp, vp, i, C.POINTER(vp)]),
+        "jdsp_gmm_destroy": (i, [vp]),
+        "jdsp_gmm_score_dev": (i, [vp, vp, l, vp, l, vp, vp]),
+        "jdsp_gmm_score": (i, [vp, vp, vp, l, vp, vp]),
+        "jdsp_hmm_create": (i, [vp, vp, i, C.POINTER(vp)]),
+        "jdsp_hmm_destroy": (i, [vp]),
+        "jdsp_hmm_reserve": (i, [vp, l]),
+        "jdsp_hmm_viterbi_dev": (i, [vp, vp, l, vp, l, vp, vp, vp, vp]),
+        "jdsp_hmm_viterbi": (i, [vp, vp, vp, l, vp, vp, vp]),
         "jdsp_mfcc_native_cfg": (i, [vp]),
         "jdsp_mfcc_create": (i, [vp, vp, C.POINTER(vp)]),
         "jdsp_mfcc_destroy": (i, [vp]),

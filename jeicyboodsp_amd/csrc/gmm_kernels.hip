@@ -1,0 +1,202 @@
+// gmm_kernels.hip -- GMM scoring and the HMM recursion on device-resident MFCC vectors (gfx950).
+//
+//   gmm_score_kernel     Recognition() + the class arg-max   GMMAlgorithm_Test_Auto_ver2.cpp:113-127,:151-162
+//   gmm_emission_kernel  sum_k alpa[k] probability_k(x)       Viterbi_version1.cpp:183-185,:193-195
+//   hmm_trellis_kernel   HMMRecognition()                      Viterbi_version1.cpp:157-246
+//
+// Everything is FP64 like the reference (these are a few hundred flops per 96-byte vector: neither HBM nor
+// the FP64 pipe is stressed; the point of the device path is that the MFCCs never leave HBM).  A GMM's
+// parameters are wave-uniform (one class per wave), so they come in through scalar loads.
+#include "jdsp_internal.h"
+
+namespace jdsp {
+
+// probability() (GMMTest:216-235 = Viterbi:248-267) for mixture k of the packed record `g`, and the
+// alpa-weighted sum over the four mixtures.  No FMA contraction: the products and sums round one by one as
+// in the reference's x87-free double arithmetic.
+__device__ __forceinline__ double gmm_mixture(const double (&x)[12], const double *__restrict__ g)
+{
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const double *E = g + kGmmEig + 48 * k;
+        double y[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int i = 0; i < 12; i++) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) y[j] = __dadd_rn(y[j], __dmul_rn(x[i], E[4 * i + j]));      // :228
+        }
+        double p = 1.0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {                                                               // :230-233
+            const double c = g[kGmmVar + 4 * k + i];
+            const double d = __dsub_rn(y[i], g[kGmmMean + 4 * k + i]);
+            const double e = exp(__ddiv_rn(__dmul_rn(-0.5, __dmul_rn(d, d)), c));
+            p = __dmul_rn(p, __dmul_rn(g[kGmmCoef + 4 * k + i], e));
+        }
+        t = __dadd_rn(t, __dmul_rn(g[kGmmAlpa + k], p));                                            // :156
+    }
+    return t;
+}
+
+__device__ __forceinline__ void load_vector(const double *__restrict__ feats, long f, double (&x)[12])
+{
+    const double2 *p = reinterpret_cast<const double2 *>(feats + 12 * f);                          // 96 B, 16-aligned
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        const double2 v = p[i];
+        x[2 * i] = v.x;
+        x[2 * i + 1] = v.y;
+    }
+}
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// One workgroup (4 waves) per utterance; wave w scores the classes w, w+4, ...: lanes stride over the
+// utterance's frames, a fixed butterfly adds the 64 partial sums.  Thread 0 then runs the reference's
+// `dMax < score` scan.  The sum over frames is therefore associated differently from the reference's
+// running sum (O(1e-16) relative per term).
+__device__ __forceinline__ long clamp_offset(long long v, long n) { return v < 0 ? 0 : (v > n ? n : (long)v); }
+
+__global__ __launch_bounds__(256) void gmm_score_kernel(const double *__restrict__ feats, long n_frames,
+                                                        const long long *__restrict__ utt_first, long n_utts,
+                                                        const double *__restrict__ gmm, int n_classes,
+                                                        double *__restrict__ scores, int *__restrict__ best)
+{
+    __shared__ double sc[kGmmMaxClasses];
+    const long u = blockIdx.x;
+    if (u >= n_utts) return;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // offsets outside [0, n_frames] are the caller's error; clamped so that no vector outside feats is read
+    const long first = clamp_offset(utt_first[u], n_frames), last = clamp_offset(utt_first[u + 1], n_frames);
+    for (int c = wave; c < n_classes; c += 4) {
+        const double *g = gmm + (size_t)c * kGmmRecord;
+        double acc = 0.0;
+        for (long f = first + lane; f < last; f += 64) {
+            double x[12];
+            load_vector(feats, f, x);
+            acc += log(gmm_mixture(x, g));                                                          // :158
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) {
+            const double s = acc / (double)(last - first);                                          // :161
+            sc[c] = s;
+            scores[u * n_classes + c] = s;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && best) {
+        double mx = sc[0];
+        int arg = 0;
+        for (int c = 1; c < n_classes; c++)
+            if (mx < sc[c]) { mx = sc[c]; arg = c; }                                                // :117-124
+        best[u] = arg;
+    }
+}
+
+// b[f][g] for every frame f and every state GMM g (n_g = models * 6); 64 frames x one g per wave.
+__global__ __launch_bounds__(64) void gmm_emission_kernel(const double *__restrict__ feats, long n_frames,
+                                                          const double *__restrict__ gmm, int n_g,
+                                                          double *__restrict__ b)
+{
+    const long f = (long)blockIdx.x * 64 + threadIdx.x;
+    const int gi = blockIdx.y;
+    if (f >= n_frames) return;
+    double x[12];
+    load_vector(feats, f, x);
+    b[f * n_g + gi] = gmm_mixture(x, gmm + (size_t)gi * kGmmRecord);
+}
+
+// One thread per utterance, models in turn: the six-state recursion as the reference writes it
+// (log of the previous accumulated log probability, :196; first-u assignment then `<`, :198-204),
+// the per-frame arg-max state (:212-221) as the "decoding result", the frame-1 maximum as the score,
+// and the model arg-max of :119-126.
+__global__ __launch_bounds__(64) void hmm_trellis_kernel(const double *__restrict__ b,
+                                                         const long long *__restrict__ utt_first, long n_utts,
+                                                         long n_frames_total, const double *__restrict__ log_trans,
+                                                         int n_models, double log_init, double *__restrict__ scores,
+                                                         int *__restrict__ best, int *__restrict__ path,
+                                                         double *__restrict__ trellis)
+{
+    const long u = (long)blockIdx.x * 64 + threadIdx.x;
+    if (u >= n_utts) return;
+    const long first = clamp_offset(utt_first[u], n_frames_total), last = clamp_offset(utt_first[u + 1], n_frames_total);
+    const int n_g = n_models * 6;
+    double mx_model = 0.0;
+    int arg_model = 0;
+    for (int mdl = 0; mdl < n_models; mdl++) {
+        const double *lt = log_trans + 36 * mdl;
+        double prev[6], cur[6];
+        double ret = 0.0;
+        for (long f = first; f < last; f++) {
+            const double *bf = b + f * n_g + 6 * mdl;
+            int arg = 0;
+            if (f == first) {
+#pragma unroll
+                for (int m = 0; m < 6; m++) cur[m] = log(bf[m]) + log_init;                         // :186
+            } else {
+                double lp[6];
+#pragma unroll
+                for (int q = 0; q < 6; q++) lp[q] = log(prev[q]);
+#pragma unroll
+                for (int m = 0; m < 6; m++) {
+                    const double lb = log(bf[m]);
+                    double v = (lp[0] + lt[m]) + lb;                                                // :196, u = 0
+#pragma unroll
+                    for (int q = 1; q < 6; q++) {
+                        const double t = (lp[q] + lt[6 * q + m]) + lb;
+                        if (v < t) v = t;                                                           // :201
+                    }
+                    cur[m] = v;
+                }
+                double mx = cur[0];
+#pragma unroll
+                for (int m = 1; m < 6; m++)
+                    if (cur[m] > mx) { mx = cur[m]; arg = m; }                                      // :217
+                if (f == first + 1) ret = mx;
+            }
+            if (path) path[(size_t)mdl * n_frames_total + f] = arg;
+#pragma unroll
+            for (int m = 0; m < 6; m++) {
+                if (trellis) trellis[((size_t)mdl * 6 + m) * n_frames_total + f] = cur[m];
+                prev[m] = cur[m];
+            }
+        }
+        if (scores) scores[u * n_models + mdl] = ret;
+        if (mdl == 0) { mx_model = ret; arg_model = 0; }
+        else if (mx_model < ret) { mx_model = ret; arg_model = mdl; }                               // Viterbi:119-126
+    }
+    if (best) best[u] = arg_model;
+}
+
+int launch_gmm_score(hipStream_t stream, const double *feats, long n_frames, const long long *utt_first, long n_utts,
+                     const double *gmm, int n_classes, double *scores, int *best)
+{
+    if (n_utts <= 0) return 0;
+    hipLaunchKernelGGL(gmm_score_kernel, dim3((unsigned)n_utts), dim3(256), 0, stream, feats, n_frames, utt_first, n_utts, gmm,
+                       n_classes, scores, best);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+int launch_hmm_viterbi(hipStream_t stream, const double *feats, long n_frames, const long long *utt_first, long n_utts,
+                       const double *gmm, const double *log_trans, int n_models, double log_init, double *b,
+                       double *scores, int *best, int *path, double *trellis)
+{
+    if (n_utts <= 0) return 0;
+    if (n_frames > 0) {
+        hipLaunchKernelGGL(gmm_emission_kernel, dim3((unsigned)((n_frames + 63) / 64), (unsigned)(n_models * 6)),
+                           dim3(64), 0, stream, feats, n_frames, gmm, n_models * 6, b);
+        if (hipGetLastError() != hipSuccess) return -1;
+    }
+    hipLaunchKernelGGL(hmm_trellis_kernel, dim3((unsigned)((n_utts + 63) / 64)), dim3(64), 0, stream, b, utt_first,
+                       n_utts, n_frames, log_trans, n_models, log_init, scores, best, path, trellis);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+}  // namespace jdsp

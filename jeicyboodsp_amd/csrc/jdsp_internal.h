@@ -170,6 +170,15 @@ int launch_mvdrn(hipStream_t s, const short *pcm, long chan_stride, int n_mics, 
 int launch_pitch(hipStream_t s, const short *pcm, long n_blocks, const short *prev_block, const float2 *table, int *arg,
                  float *rmax, float *autocorr);
 // mfcc_kernels.hip
+// ---- GMM / HMM (gmm_kernels.hip) ----
+// packed per-GMM record (doubles): alpa[4], mean[4][4], var[4][4], coef[4][4], eig[4][12][4]
+constexpr int kGmmAlpa = 0, kGmmMean = 4, kGmmVar = 20, kGmmCoef = 36, kGmmEig = 52, kGmmRecord = 244;
+constexpr int kGmmMaxClasses = 256;
+int launch_gmm_score(hipStream_t stream, const double *feats, long n_frames, const long long *utt_first, long n_utts,
+                     const double *gmm, int n_classes, double *scores, int *best);
+int launch_hmm_viterbi(hipStream_t stream, const double *feats, long n_frames, const long long *utt_first, long n_utts,
+                       const double *gmm, const double *log_trans, int n_models, double log_init, double *b,
+                       double *scores, int *best, int *path, double *trellis);
 int launch_mfcc(hipStream_t s, const short *pcm, const long long *starts, long n_frames, const MfccDev &p,
                 const float2 *table, double *feats);
 
@@ -208,6 +217,21 @@ struct jdsp_mfcc {
     void *blob = nullptr;                 // one device allocation holding every table
     std::vector<double> mel_freqs, fbank;
     std::vector<int> fi_bins;
+};
+
+struct jdsp_gmm {
+    jdsp_ctx *ctx = nullptr;
+    int n_classes = 0;
+    double *records = nullptr;            // [n_classes][kGmmRecord]
+};
+
+struct jdsp_hmm {
+    jdsp_ctx *ctx = nullptr;
+    int n_models = 0;
+    double *records = nullptr;            // [n_models * 6][kGmmRecord]
+    double *log_trans = nullptr;          // [n_models][6][6], log() taken on the host
+    double *emission = nullptr;           // scratch [frames][n_models * 6], grown on demand
+    long emission_frames = 0;
 };
 
 struct jdsp_fastconv {

@@ -68,6 +68,12 @@ class Engine:
     def mfcc(self, **cfg):
         return Mfcc(self, **cfg)
 
+    def gmm(self, classes):
+        return Gmm(self, classes)
+
+    def hmm(self, models):
+        return Hmm(self, models)
+
     def denoiser(self, mode):
         return Denoiser(self, mode)
 
@@ -353,6 +359,114 @@ class Mfcc:
                                         frame_start.ctypes.data_as(C.c_void_p) if frame_start is not None else None,
                                         n_frames, out.ctypes.data_as(C.c_void_p)))
         return out
+
+
+# numpy views of the reference's parameter records (GMMAlgorithm_Test_Auto_ver2.cpp:29-34,
+# Viterbi_version1.cpp:30-40): np.fromfile(path, GMM_PARAM) reads a parameter file
+GMM_PARAM = np.dtype([("alpa", "<f8", (4,)), ("mean", "<f8", (4, 12)), ("covariance", "<f8", (4, 12, 12)),
+                      ("eigenVector", "<f8", (4, 12, 4))])
+HMM_PARAM = np.dtype([("gMMParam", GMM_PARAM, (6,)), ("transProb", "<f8", (6, 6))])
+
+
+def _vp(a):
+    if a is None:
+        return None
+    if _is_torch(a):
+        return C.c_void_p(a.data_ptr())
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class _Child:
+    _destroy = None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            type(self)._destroy(self._h)
+            self._h = None
+            if self in self.eng._children:
+                self.eng._children.remove(self)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Gmm(_Child):
+    """GMM scoring (jdsp_gmm): Recognition() of GMMAlgorithm_Test_Auto_ver2.cpp for batches of utterances.
+    `classes`: numpy array of GMM_PARAM records, one per class."""
+    _destroy = staticmethod(lambda h: L.jdsp_gmm_destroy(h))
+
+    def __init__(self, engine, classes):
+        self.eng = engine
+        classes = np.ascontiguousarray(classes, GMM_PARAM).reshape(-1)
+        self.n_classes = len(classes)
+        h = C.c_void_p()
+        engine._ck(L.jdsp_gmm_create(engine._h, _vp(classes), self.n_classes, C.byref(h)))
+        self._h = h
+        engine._children.append(self)
+
+    def score(self, feats, utt_first):
+        """feats [n_vectors, 12] float64, utt_first [n_utts + 1] int64 -> (scores [n_utts, n_classes], best [n_utts]).
+        torch CUDA tensors stay on the device; numpy arrays go through the host entry."""
+        n_utts = len(utt_first) - 1
+        if _is_torch(feats):
+            import torch
+            assert feats.is_cuda and feats.dtype == torch.float64 and feats.is_contiguous()
+            assert utt_first.is_cuda and utt_first.dtype == torch.int64
+            scores = torch.empty((n_utts, self.n_classes), dtype=torch.float64, device=feats.device)
+            best = torch.empty((n_utts,), dtype=torch.int32, device=feats.device)
+            self.eng._use_torch_stream()
+            self.eng._ck(L.jdsp_gmm_score_dev(self._h, _vp(feats), feats.shape[0], _vp(utt_first), n_utts, _vp(scores),
+                                              _vp(best)))
+            return scores, best
+        feats = np.ascontiguousarray(feats, np.float64)
+        utt_first = np.ascontiguousarray(utt_first, np.int64)
+        scores = np.empty((n_utts, self.n_classes), np.float64)
+        best = np.empty((n_utts,), np.int32)
+        self.eng._ck(L.jdsp_gmm_score(self._h, _vp(feats), _vp(utt_first), n_utts, _vp(scores), _vp(best)))
+        return scores, best
+
+
+class Hmm(_Child):
+    """Six-state HMM recursion (jdsp_hmm): HMMRecognition() of Viterbi_version1.cpp for batches of utterances.
+    `models`: numpy array of HMM_PARAM records."""
+    _destroy = staticmethod(lambda h: L.jdsp_hmm_destroy(h))
+
+    def __init__(self, engine, models):
+        self.eng = engine
+        models = np.ascontiguousarray(models, HMM_PARAM).reshape(-1)
+        self.n_models = len(models)
+        h = C.c_void_p()
+        engine._ck(L.jdsp_hmm_create(engine._h, _vp(models), self.n_models, C.byref(h)))
+        self._h = h
+        engine._children.append(self)
+
+    def viterbi(self, feats, utt_first, want_path=True, want_trellis=False):
+        """-> (scores [n_utts, n_models], best [n_utts], path [n_models, n_vectors] or None[, trellis])."""
+        n_utts = len(utt_first) - 1
+        n_frames = feats.shape[0]
+        if _is_torch(feats):
+            import torch
+            assert feats.is_cuda and feats.dtype == torch.float64 and feats.is_contiguous()
+            assert utt_first.is_cuda and utt_first.dtype == torch.int64
+            dev = feats.device
+            scores = torch.empty((n_utts, self.n_models), dtype=torch.float64, device=dev)
+            best = torch.empty((n_utts,), dtype=torch.int32, device=dev)
+            path = torch.zeros((self.n_models, n_frames), dtype=torch.int32, device=dev) if want_path else None
+            trellis = torch.zeros((self.n_models, 6, n_frames), dtype=torch.float64, device=dev) if want_trellis else None
+            self.eng._use_torch_stream()
+            self.eng._ck(L.jdsp_hmm_viterbi_dev(self._h, _vp(feats), n_frames, _vp(utt_first), n_utts, _vp(scores),
+                                                _vp(best), _vp(path), _vp(trellis)))
+            return (scores, best, path, trellis) if want_trellis else (scores, best, path)
+        feats = np.ascontiguousarray(feats, np.float64)
+        utt_first = np.ascontiguousarray(utt_first, np.int64)
+        scores = np.empty((n_utts, self.n_models), np.float64)
+        best = np.empty((n_utts,), np.int32)
+        path = np.zeros((self.n_models, n_frames), np.int32) if want_path else None
+        self.eng._ck(L.jdsp_hmm_viterbi(self._h, _vp(feats), _vp(utt_first), n_utts, _vp(scores), _vp(best), _vp(path)))
+        return scores, best, path
 
 
 class FastConv:

@@ -724,3 +724,95 @@ long orc_mvdrn_stream(const short *pcm, long chan_stride, int n_mics, long n_blo
     free(x); free(X); free(Y); free(y); free(R);
     return n_out;
 }
+
+
+/* ======================================================================================
+ * GMM scoring / HMM recursion
+ * ====================================================================================== */
+
+/* GMMAlgorithm_Test_Auto_ver2.cpp:216-235 (the live #if 1 branch) = Viterbi_version1.cpp:248-267. */
+double orc_gmm_probability(const double *x, const double *mean, const double *cov, const double *eig)
+{
+    double y[4];
+    for (int j = 0; j < 4; j++) {                       /* InputMatrx * EigenMatrx, :228 */
+        double a = 0.0;
+        for (int i = 0; i < 12; i++) a += x[i] * eig[i * 4 + j];
+        y[j] = a;
+    }
+    double p = 1.0;
+    for (int i = 0; i < 4; i++) {                       /* :230-233 */
+        const double c = cov[i * 12 + i];
+        const double d = y[i] - mean[i];
+        p *= (1.0 / sqrt(2.0 * PI_APPS)) * (1.0 / sqrt(c)) * exp((-1 / 2.0) * (d * d) / c);
+    }
+    return p;
+}
+
+static double gmm_mixture(const double *x, const orc_gmm_param *g)
+{
+    double t = 0.0;
+    for (int k = 0; k < 4; k++)                         /* GMMTest:155-157, Viterbi:183-185,:193-195 */
+        t += g->alpa[k] * orc_gmm_probability(x, g->mean[k], &g->covariance[k][0][0], &g->eigenVector[k][0][0]);
+    return t;
+}
+
+/* GMMTest:151-162 */
+double orc_gmm_recognition(const double *feats, long n_frames, const orc_gmm_param *g)
+{
+    double acc = 0.0;
+    for (long i = 0; i < n_frames; i++) acc += log(gmm_mixture(feats + 12 * i, g));
+    return acc / (double)n_frames;
+}
+
+/* GMMTest:113-127 */
+int orc_gmm_classify(const double *feats, long n_frames, const orc_gmm_param *classes, int n_classes,
+                     double *scores)
+{
+    double best = 0.0;
+    int arg = 0;
+    for (int u = 0; u < n_classes; u++) {
+        const double s = orc_gmm_recognition(feats, n_frames, &classes[u]);
+        if (scores) scores[u] = s;
+        if (u == 0) { best = s; arg = 0; }
+        else if (best < s) { best = s; arg = u; }
+    }
+    return arg;
+}
+
+/* Viterbi:157-246 */
+double orc_hmm_viterbi(const double *feats, long n_frames, const orc_hmm_param *h, int *path, double *trellis)
+{
+    enum { S = 6 };
+    double prev[S], cur[S];
+    double ret = 0.0;                                   /* dTempProb's initial value, :159 */
+    if (path) memset(path, 0, sizeof(int) * (size_t)(n_frames > 0 ? n_frames : 0));
+    /* the arg-max of :209-225 only reads column i of the trellis, so it is taken as each column is finished;
+     * the reference walks i downwards and returns the value found last, i.e. at i = 1 */
+    for (long i = 0; i < n_frames; i++) {
+        const double *x = feats + 12 * i;
+        if (i == 0) {
+            for (int m = 0; m < S; m++)                 /* :182-187 */
+                cur[m] = log(gmm_mixture(x, &h->gMMParam[m])) + log(1.0 / (double)S);
+        } else {
+            for (int m = 0; m < S; m++) {               /* :190-206 */
+                const double b = gmm_mixture(x, &h->gMMParam[m]);
+                for (int u = 0; u < S; u++) {
+                    const double t = log(prev[u]) + log(h->transProb[u][m]) + log(b);
+                    if (u == 0) cur[m] = t;
+                    else if (cur[m] < t) cur[m] = t;
+                }
+            }
+            double best = cur[0];                       /* :212-221 */
+            int arg = 0;
+            for (int m = 1; m < S; m++)
+                if (cur[m] > best) { best = cur[m]; arg = m; }
+            if (path) path[i] = arg;
+            if (i == 1) ret = best;
+        }
+        for (int m = 0; m < S; m++) {
+            if (trellis) trellis[(size_t)m * n_frames + i] = cur[m];
+            prev[m] = cur[m];
+        }
+    }
+    return ret;
+}

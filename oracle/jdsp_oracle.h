@@ -135,6 +135,43 @@ long orc_mvdr_stream(const short *left, const short *right, long n_blocks, doubl
 long orc_mvdrn_stream(const short *pcm, long chan_stride, int n_mics, long n_blocks, const double *delays,
                       double loading, short *out, double *pre_cast);
 
+/* GMM scoring and the HMM recursion on MFCC vectors.
+ * Both programs use Eigen only for one (1 x 12)(12 x 4) product per call (GMMAlgorithm_Test_Auto_ver2.cpp:228,
+ * Viterbi_version1.cpp:260); Eigen is not in this image, so these programs cannot be compiled here and the
+ * product is restated as the in-order sum over the 12 inputs ("parity unpinned at the Eigen boundary": an
+ * Eigen build may associate that sum differently, an O(1e-16) relative effect).
+ * The structs are the programs' own parameter records (GMMTest:29-34, Viterbi:30-40), byte for byte: the
+ * parameter files are arrays of them (GMMTest:76, Viterbi:80). */
+typedef struct {
+    double alpa[4];
+    double mean[4][12];
+    double covariance[4][12][12];
+    double eigenVector[4][12][4];
+} orc_gmm_param;
+typedef struct {
+    orc_gmm_param gMMParam[6];
+    double transProb[6][6];
+} orc_hmm_param;
+
+/* probability() (GMMTest:216-235 = Viterbi:248-267): project the 12 features on 4 principal axes, product of
+ * four univariate normal densities with mean[i], covariance[i][i], i < 4 (PI = 3.141592). */
+double orc_gmm_probability(const double *x, const double *mean, const double *cov /*[12][12]*/,
+                           const double *eig /*[12][4]*/);
+/* Recognition() (GMMTest:151-162): mean over the frames of log(sum_k alpa[k] * probability_k). */
+double orc_gmm_recognition(const double *feats, long n_frames, const orc_gmm_param *g);
+/* The class loop of main() (GMMTest:113-127): scores[u] for every class and the arg-max with the reference's
+ * `dMax < score` update rule (first maximum wins; a NaN never replaces, a leading NaN is never replaced). */
+int orc_gmm_classify(const double *feats, long n_frames, const orc_gmm_param *classes, int n_classes,
+                     double *scores);
+/* HMMRecognition() (Viterbi:157-246) as written, including what it does rather than what a Viterbi decoder
+ * would: the recursion adds log(previous accumulated LOG probability) (:196), so a negative accumulated value
+ * turns the trellis into NaN from the second frame on; the back-pointer is overwritten by the next frame's
+ * arg-max (:212-224), so the "decoding result" is the per-frame arg-max state for frames 1..n-1 (frame 0 stays
+ * 0) and the returned value is the largest trellis entry of frame 1 (0 when n_frames < 2).  The one-past-the-end
+ * write of dDecodingReslt[iFileLen-1] (:164,:223) lands in path[n_frames-1] here (path has n_frames entries).
+ * trellis (may be NULL): [6][n_frames] as sProb.dHMMProb. */
+double orc_hmm_viterbi(const double *feats, long n_frames, const orc_hmm_param *h, int *path, double *trellis);
+
 #ifdef __cplusplus
 }
 #endif

@@ -25,6 +25,12 @@ class MfccCfg(C.Structure):
                 ("half_rate", C.c_double), ("preemph", C.c_double)]
 
 
+# the reference's parameter records (GMMAlgorithm_Test_Auto_ver2.cpp:29-34, Viterbi_version1.cpp:30-40)
+GMM_PARAM = np.dtype([("alpa", "<f8", (4,)), ("mean", "<f8", (4, 12)), ("covariance", "<f8", (4, 12, 12)),
+                      ("eigenVector", "<f8", (4, 12, 4))])
+HMM_PARAM = np.dtype([("gMMParam", GMM_PARAM, (6,)), ("transProb", "<f8", (6, 6))])
+
+
 def _p(a, t):
     return a.ctypes.data_as(t)
 
@@ -70,11 +76,48 @@ class Oracle:
         L.orc_mvdrn_stream.argtypes = [_c_short_p, C.c_long, C.c_int, C.c_long, _c_double_p, C.c_double, _c_short_p,
                                        _c_double_p]
         L.orc_mvdrn_stream.restype = C.c_long
+        L.orc_gmm_probability.argtypes = [_c_double_p, _c_double_p, _c_double_p, _c_double_p]
+        L.orc_gmm_probability.restype = C.c_double
+        L.orc_gmm_recognition.argtypes = [_c_double_p, C.c_long, C.c_void_p]
+        L.orc_gmm_recognition.restype = C.c_double
+        L.orc_gmm_classify.argtypes = [_c_double_p, C.c_long, C.c_void_p, C.c_int, _c_double_p]
+        L.orc_gmm_classify.restype = C.c_int
+        L.orc_hmm_viterbi.argtypes = [_c_double_p, C.c_long, C.c_void_p, _c_int_p, _c_double_p]
+        L.orc_hmm_viterbi.restype = C.c_double
         L.orc_mfcc_native_cfg.argtypes = [C.POINTER(MfccCfg)]
         L.orc_mel_init.argtypes = [C.POINTER(MfccCfg), _c_double_p, _c_int_p, _c_double_p]
         L.orc_mfcc_frame.argtypes = [C.POINTER(MfccCfg), _c_int_p, _c_double_p, _c_short_p, _c_double_p]
         L.orc_mfcc_stream.argtypes = [C.POINTER(MfccCfg), _c_short_p, C.c_long, _c_double_p]
         L.orc_mfcc_stream.restype = C.c_long
+
+    # --- GMM scoring / HMM recursion (records: numpy arrays of GMM_PARAM / HMM_PARAM) ------------
+    def gmm_probability(self, x, mean, cov, eig):
+        x = np.ascontiguousarray(x, np.float64)
+        mean = np.ascontiguousarray(mean, np.float64)
+        cov = np.ascontiguousarray(cov, np.float64)
+        eig = np.ascontiguousarray(eig, np.float64)
+        return self.lib.orc_gmm_probability(_p(x, _c_double_p), _p(mean, _c_double_p), _p(cov, _c_double_p),
+                                            _p(eig, _c_double_p))
+
+    def gmm_classify(self, feats, classes):
+        """(scores [n_classes], arg) for one utterance [n, 12]."""
+        feats = np.ascontiguousarray(feats, np.float64)
+        classes = np.ascontiguousarray(classes, GMM_PARAM).reshape(-1)
+        scores = np.zeros(len(classes), np.float64)
+        arg = self.lib.orc_gmm_classify(_p(feats, _c_double_p), feats.shape[0], classes.ctypes.data_as(C.c_void_p),
+                                        len(classes), _p(scores, _c_double_p))
+        return scores, arg
+
+    def hmm_viterbi(self, feats, model):
+        """(returned value, path [n], trellis [6, n]) for one utterance and one HMM_PARAM record."""
+        feats = np.ascontiguousarray(feats, np.float64)
+        model = np.ascontiguousarray(model, HMM_PARAM).reshape(-1)
+        n = feats.shape[0]
+        path = np.zeros(max(n, 1), np.int32)
+        trellis = np.zeros((6, max(n, 1)), np.float64)
+        ret = self.lib.orc_hmm_viterbi(_p(feats, _c_double_p), n, model.ctypes.data_as(C.c_void_p), _p(path, _c_int_p),
+                                       _p(trellis, _c_double_p))
+        return ret, path[:n], trellis[:, :n]
 
     # --- FFTAlgorithm_ver2 --------------------------------------------------
     def bitrev_table(self, n_fft, block_len=None):
