@@ -348,7 +348,7 @@ int jdsp_hmm_viterbi_dev(jdsp_hmm *h, const double *feats_dev, long n_frames, co
                          long n_utts, double *scores_dev, int *best_dev, int *path_dev, double *trellis_dev);
 /* host entry: utt_first_host[0] must be 0 and utt_first_host[n_utts] is the total number of vectors */
 int jdsp_hmm_viterbi(jdsp_hmm *h, const double *feats_host, const int64_t *utt_first_host, long n_utts,
-                     double *scores_host, int *best_host, int *path_host);
+                     double *scores_host, int *best_host, int *path_host, double *trellis_host);
 
 #ifdef __cplusplus
 }

@@ -76,7 +76,7 @@ def _load():
         "jdsp_hmm_destroy": (i, [vp]),
         "jdsp_hmm_reserve": (i, [vp, l]),
         "jdsp_hmm_viterbi_dev": (i, [vp, vp, l, vp, l, vp, vp, vp, vp]),
-        "jdsp_hmm_viterbi": (i, [vp, vp, vp, l, vp, vp, vp]),
+        "jdsp_hmm_viterbi": (i, [vp, vp, vp, l, vp, vp, vp, vp]),
         "jdsp_mfcc_native_cfg": (i, [vp]),
         "jdsp_mfcc_create": (i, [vp, vp, C.POINTER(vp)]),
         "jdsp_mfcc_destroy": (i, [vp]),

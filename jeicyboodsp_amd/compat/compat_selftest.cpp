@@ -1,6 +1,6 @@
 // compat_selftest.cpp -- drives the reference-signature functions exactly the way the
 // reference main()s do (one block per call) and dumps what they return, for tests/ to compare
-// with the CPU checker.  usage: compat_selftest <ss|wf|conv|mfcc|fft> in.raw out.bin [taps.f64]
+// with the CPU checker.  usage: compat_selftest <ss|wf|conv|mfcc|pitch|fft|gmm|hmm> in.raw out.bin [taps.f64 | params.bin]
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -63,6 +63,35 @@ int main(int argc, char **argv)
             int a = JeicybooLastPitchArg();
             fwrite(&a, 4, 1, out);
         }
+    } else if (!strcmp(what, "gmm") || !strcmp(what, "hmm")) {
+        // in.raw = raw double[12] vectors of one utterance (an .mfc file), argv[4] = parameter records
+        if (argc < 5) return 1;
+        const size_t n = pcm.size() * sizeof(short) / sizeof(double) / 12;
+        std::vector<double *> rows(n);
+        for (size_t i = 0; i < n; i++) rows[i] = reinterpret_cast<double *>(pcm.data()) + 12 * i;
+        FILE *fp = fopen(argv[4], "rb");
+        if (!fp) { perror(argv[4]); return 1; }
+        if (!strcmp(what, "gmm")) {
+            // the class loop of GMMAlgorithm_Test_Auto_ver2.cpp:113-127
+            GMMParameter g;
+            double dMax = 0;
+            int dArg = 0, u = 0;
+            while (fread(&g, sizeof(g), 1, fp) == 1) {
+                const double s = Recognition(rows.data(), &g, (int)n);
+                if (u == 0) { dMax = s; dArg = 0; }
+                else if (dMax < s) { dMax = s; dArg = u; }
+                fwrite(&s, 8, 1, out);
+                u++;
+            }
+            const double arg = dArg;
+            fwrite(&arg, 8, 1, out);
+        } else {
+            HMMParameter hmm;
+            if (fread(&hmm, sizeof(hmm), 1, fp) != 1) return 1;
+            const double s = HMMRecognition(rows.data(), &hmm, (int)n);
+            fwrite(&s, 8, 1, out);
+        }
+        fclose(fp);
     } else if (!strcmp(what, "fft")) {
         std::vector<COMPLEX> a(512), b(512);
         short bits[512];

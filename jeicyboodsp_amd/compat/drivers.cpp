@@ -1,6 +1,6 @@
 // drivers.cpp -- the reference programs' command lines over the BATCHED C ABI: each program
 // reads its whole input like the reference's fread() loop would, makes ONE engine call per
-// stream and writes the reference's output format.  Built as seven executables (Makefile):
+// stream and writes the reference's output format.  Built as nine executables (Makefile):
 //
 //   jdsp_fftalg   in.wav  out.raw            FFTAlgorithm_ver2.cpp main()            (:30-92)
 //   jdsp_specsub  in.raw  out.raw            SpectralSubtraction_final.cpp main()    (:62-119)
@@ -11,6 +11,8 @@
 //   jdsp_mfcc     list.txt                   MFCCFeatureExtraction_auto_version1.cpp main() (:44-114)
 //   jdsp_mvdr     left.wav right.wav out.raw BeamForming_MVDR_ver1.cpp main()        (:47-122)
 //   jdsp_pitch1   in.wav                     PitchEstimation_method1.cpp main()      (:33-67); prints like :109
+//   jdsp_gmmtest  test_list.txt params.bin   GMMAlgorithm_Test_Auto_ver2.cpp main()  (:46-149)
+//   jdsp_viterbi  test_list.txt params.bin   Viterbi_version1.cpp main()             (:51-155)
 //
 // File conventions kept from the reference: raw little-endian int16 PCM; a 44-byte WAV header
 // is skipped by fftalg/conv3d/mfcc (FFT:59, 3D:79, MFCC:83) and NOT by specsub/wiener
@@ -186,6 +188,118 @@ static int run_pitch1(int argc, char **argv)
     return 0;
 }
 
+// ---- GMMAlgorithm_Test_Auto_ver2.cpp / Viterbi_version1.cpp ------------------------------------------
+// Both mains read: argv[1] = a text file naming NUM_OF_CLASS class list files, each naming .mfc files of raw
+// double[12] vectors (what jdsp_mfcc writes); argv[2] = NUM_OF_CLASS parameter records.  The reference's
+// `while (!feof(f)) fscanf(f, "%s", name)` loops run once more after the last name when the file ends in a
+// newline and then dereference a NULL FILE*; here a list simply ends at its last name.
+static std::vector<std::string> read_names(const char *path)
+{
+    std::vector<std::string> names;
+    FILE *f = open_or_die(path, "rb");
+    char tok[255];
+    while (fscanf(f, "%254s", tok) == 1) names.push_back(tok);
+    fclose(f);
+    return names;
+}
+
+struct MfcBatch {
+    std::vector<double> feats;
+    std::vector<int64_t> first{0};
+    std::vector<int> list_of;                 // which class list (0-based) each utterance came from
+};
+
+static MfcBatch read_mfc_lists(const std::vector<std::string> &lists, size_t from, size_t count)
+{
+    MfcBatch b;
+    for (size_t i = 0; i < count; i++) {
+        for (const std::string &mfc : read_names(lists[from + i].c_str())) {
+            FILE *f = open_or_die(mfc.c_str(), "rb");
+            fseek(f, 0L, SEEK_END);
+            const long n = ftell(f) / (long)sizeof(double) / 12;                        // GMMTest:98-101
+            fseek(f, 0L, SEEK_SET);
+            const size_t at = b.feats.size();
+            b.feats.resize(at + (size_t)n * 12);
+            if (n > 0 && fread(&b.feats[at], sizeof(double), (size_t)n * 12, f) != (size_t)n * 12) die("short .mfc read");
+            fclose(f);
+            b.first.push_back(b.first.back() + n);
+            b.list_of.push_back((int)i);
+        }
+    }
+    return b;
+}
+
+static int env_int(const char *name, int dflt)
+{
+    const char *v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+
+static int run_gmmtest(int argc, char **argv)
+{
+    if (argc != 3) { fprintf(stderr, "usage: jdsp_gmmtest test_list.txt params.bin\n"); return 1; }
+    for (int i = 1; i < 3; i++) printf("%d-th path %s \n", i, argv[i]);                 // GMMTest:62-63
+    const int C = env_int("JDSP_NUM_OF_CLASS", 25);                                     // GMMTest:26
+    const std::vector<std::string> lists = read_names(argv[1]);
+    FILE *fp = open_or_die(argv[2], "rb");
+    for (size_t from = 0; from + C <= lists.size(); from += C) {                        // the outer while of :72
+        std::vector<jdsp_gmm_param> params(C);
+        if (fread(params.data(), sizeof(jdsp_gmm_param), C, fp) != (size_t)C) break;    // :74-78
+        jdsp_gmm *h = nullptr;
+        CK(jdsp_gmm_create(g_ctx, params.data(), C, &h));
+        MfcBatch b = read_mfc_lists(lists, from, C);
+        const long n_utts = (long)b.list_of.size();
+        std::vector<double> scores((size_t)(n_utts > 0 ? n_utts : 1) * C);
+        std::vector<int> best((size_t)(n_utts > 0 ? n_utts : 1));
+        CK(jdsp_gmm_score(h, b.feats.data(), b.first.data(), n_utts, scores.data(), best.data()));
+        for (long u = 0; u < n_utts; u++) {
+            for (int c = 0; c < C; c++) printf(" %d-th class probability %f \n", c + 1, scores[(size_t)u * C + c]);   // :125
+            printf(" %d -th result %d \n", b.list_of[u] + 1, best[u] + 1);                                          // :127
+        }
+        jdsp_gmm_destroy(h);
+    }
+    fclose(fp);
+    return 0;
+}
+
+static int run_viterbi(int argc, char **argv)
+{
+    if (argc != 3) { fprintf(stderr, "usage: jdsp_viterbi test_list.txt params.bin\n"); return 1; }
+    for (int i = 1; i < 3; i++) printf("%d-th path %s \n", i, argv[i]);                 // Viterbi:66-67
+    const int C = env_int("JDSP_NUM_OF_CLASS", 1);                                      // Viterbi:26
+    const std::vector<std::string> lists = read_names(argv[1]);
+    FILE *fp = open_or_die(argv[2], "rb");
+    for (size_t from = 0; from + C <= lists.size(); from += C) {
+        std::vector<jdsp_hmm_param> params(C);
+        if (fread(params.data(), sizeof(jdsp_hmm_param), C, fp) != (size_t)C) break;    // :78-81
+        jdsp_hmm *h = nullptr;
+        CK(jdsp_hmm_create(g_ctx, params.data(), C, &h));
+        MfcBatch b = read_mfc_lists(lists, from, C);
+        const long n_utts = (long)b.list_of.size(), nf = (long)b.first.back();
+        std::vector<double> scores((size_t)(n_utts > 0 ? n_utts : 1) * C), trellis((size_t)C * 6 * (nf > 0 ? nf : 1));
+        std::vector<int> best((size_t)(n_utts > 0 ? n_utts : 1)), path((size_t)C * (nf > 0 ? nf : 1));
+        CK(jdsp_hmm_viterbi(h, b.feats.data(), b.first.data(), n_utts, scores.data(), best.data(), path.data(), trellis.data()));
+        for (long u = 0; u < n_utts; u++) {
+            const long a = (long)b.first[u], e = (long)b.first[u + 1];
+            for (int c = 0; c < C; c++) {                                               // HMMRecognition's printing
+                for (long i = e - 1; i > a; i--) {                                      // :209-222
+                    const int st = path[(size_t)c * nf + i];
+                    printf("max accumulated prob %f \n", trellis[((size_t)c * 6 + st) * nf + i]);
+                }
+                printf("decoding result ! \n");                                         // :227
+                // :228-230 prints the doubles of dDecodingReslt through %d (undefined); the states are printed here
+                for (long i = a; i + 1 < e; i++) printf("%d ,", path[(size_t)c * nf + i]);
+                printf("\n");
+                printf(" %d-th class probability %f \n", c + 1, scores[(size_t)u * C + c]);   // :127
+            }
+            printf(" %d -th result %d \n", b.list_of[u] + 1, best[u] + 1);                    // :129
+        }
+        jdsp_hmm_destroy(h);
+    }
+    fclose(fp);
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
     std::string prog = argv[0];
@@ -201,7 +315,9 @@ int main(int argc, char **argv)
     else if (prog == "jdsp_mfcc") rc = run_mfcc(argc, argv);
     else if (prog == "jdsp_mvdr") rc = run_mvdr(argc, argv);
     else if (prog == "jdsp_pitch1") rc = run_pitch1(argc, argv);
-    else fprintf(stderr, "unknown program name %s (expected jdsp_fftalg|jdsp_specsub|jdsp_wiener|jdsp_conv3d|jdsp_mfcc|jdsp_mvdr|jdsp_pitch1)\n", prog.c_str());
+    else if (prog == "jdsp_gmmtest") rc = run_gmmtest(argc, argv);
+    else if (prog == "jdsp_viterbi") rc = run_viterbi(argc, argv);
+    else fprintf(stderr, "unknown program name %s (expected jdsp_fftalg|jdsp_specsub|jdsp_wiener|jdsp_conv3d|jdsp_mfcc|jdsp_mvdr|jdsp_pitch1|jdsp_gmmtest|jdsp_viterbi)\n", prog.c_str());
     jdsp_destroy(g_ctx);
     return rc;
 }

@@ -204,3 +204,42 @@ void CalcPitch(short *in, int n)
 }
 int JeicybooLastPitchArg(void) { return g_pitch_arg; }
 double JeicybooLastPitchMax(void) { return g_pitch_max; }
+
+// ---- GMMAlgorithm_Test_Auto_ver2.cpp / Viterbi_version1.cpp -----------------------------------
+static std::vector<double> gather_rows(double **rows, int n)
+{
+    std::vector<double> x((size_t)(n > 0 ? n : 0) * 12);
+    for (int i = 0; i < n; i++) memcpy(&x[(size_t)i * 12], rows[i], 12 * sizeof(double));   // dpTestBuf[i][0..11]
+    return x;
+}
+
+double Recognition(double **rows, GMMParameter *param, int n)
+{
+    jdsp_gmm *h = nullptr;
+    CK(jdsp_gmm_create(JeicybooContext(), param, 1, &h));
+    const std::vector<double> x = gather_rows(rows, n);
+    const int64_t first[2] = {0, n > 0 ? n : 0};
+    double score = 0;
+    CK(jdsp_gmm_score(h, x.data(), first, 1, &score, nullptr));
+    jdsp_gmm_destroy(h);
+    return score;
+}
+
+double HMMRecognition(double **rows, HMMParameter *param, int n)
+{
+    jdsp_hmm *h = nullptr;
+    CK(jdsp_hmm_create(JeicybooContext(), param, 1, &h));
+    const std::vector<double> x = gather_rows(rows, n);
+    const int64_t first[2] = {0, n > 0 ? n : 0};
+    const size_t m = (size_t)(n > 0 ? n : 1);
+    std::vector<int> path(m, 0);
+    std::vector<double> trellis(6 * m, 0.0);
+    double score = 0;
+    CK(jdsp_hmm_viterbi(h, x.data(), first, 1, &score, nullptr, path.data(), trellis.data()));
+    jdsp_hmm_destroy(h);
+    for (int i = n - 1; i > 0; i--) printf("max accumulated prob %f \n", trellis[(size_t)path[i] * m + i]);   // :222
+    printf("decoding result ! \n");                                                                          // :227
+    for (int i = 0; i < n - 1; i++) printf("%d ,", path[i]);                                                  // :228-230
+    printf("\n");
+    return score;
+}

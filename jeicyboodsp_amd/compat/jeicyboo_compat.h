@@ -59,4 +59,17 @@ void CalcPitch(short *psInputBuffer, int iFrameCount);                          
 int JeicybooLastPitchArg(void);
 double JeicybooLastPitchMax(void);
 
+// ---- GMMAlgorithm_Test_Auto_ver2.cpp:29-34,:44 / Viterbi_version1.cpp:30-40,:49 -------------
+// The parameter records are the C ABI's (same layout as the reference's structs).  One call scores one
+// utterance against one record; the class loop of main() (GMMTest:113-127) calls Recognition once per
+// class -- jdsp_gmm_score does all classes and all utterances in one launch.  probability() (GMMTest:164)
+// is fused into the kernels and not exported; HMMRecognition prints what the reference prints
+// (Viterbi:222-231), the decoded states as integers (the reference passes doubles to %d there).
+#ifndef JEICYBOO_NO_GMM_TYPEDEFS
+typedef jdsp_gmm_param GMMParameter;
+typedef jdsp_hmm_param HMMParameter;
+#endif
+double Recognition(double **dpTestBuf, GMMParameter *pGmmParameter, int iFileLen);              // GMMTest:151
+double HMMRecognition(double **dpTestBuf, HMMParameter *pHmmParameter, int iFileLen);           // Viterbi:157
+
 #endif

@@ -209,7 +209,7 @@ int jdsp_hmm_viterbi_dev(jdsp_hmm *h, const double *feats_dev, long n_frames, co
 }
 
 int jdsp_hmm_viterbi(jdsp_hmm *h, const double *feats_host, const int64_t *utt_first_host, long n_utts,
-                     double *scores_host, int *best_host, int *path_host)
+                     double *scores_host, int *best_host, int *path_host, double *trellis_host)
 {
     if (!h) return JDSP_EINVAL;
     jdsp_ctx *ctx = h->ctx;
@@ -222,6 +222,8 @@ int jdsp_hmm_viterbi(jdsp_hmm *h, const double *feats_host, const int64_t *utt_f
     double *d_feats = nullptr, *d_scores = nullptr;
     int64_t *d_first = nullptr;
     int *d_best = nullptr, *d_path = nullptr;
+    double *d_trellis = nullptr;
+    const size_t sz_trellis = (size_t)h->n_models * 6 * (size_t)(n_frames > 0 ? n_frames : 1) * sizeof(double);
     const size_t sz_scores = (size_t)n_utts * h->n_models * sizeof(double);
     const size_t sz_path = (size_t)h->n_models * (size_t)(n_frames > 0 ? n_frames : 1) * sizeof(int);
     hipError_t e = hipMalloc(&d_feats, (size_t)(n_frames > 0 ? n_frames : 1) * 12 * sizeof(double));
@@ -229,21 +231,26 @@ int jdsp_hmm_viterbi(jdsp_hmm *h, const double *feats_host, const int64_t *utt_f
     if (e == hipSuccess) e = hipMalloc(&d_scores, sz_scores);
     if (e == hipSuccess) e = hipMalloc(&d_best, (size_t)n_utts * sizeof(int));
     if (e == hipSuccess && path_host) e = hipMalloc(&d_path, sz_path);
+    if (e == hipSuccess && trellis_host) e = hipMalloc(&d_trellis, sz_trellis);
     if (e == hipSuccess && n_frames > 0)
         e = hipMemcpyAsync(d_feats, feats_host, (size_t)n_frames * 12 * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess)
         e = hipMemcpyAsync(d_first, utt_first_host, (size_t)(n_utts + 1) * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream);
     int rc = JDSP_OK;
-    if (e == hipSuccess) rc = jdsp_hmm_viterbi_dev(h, d_feats, n_frames, d_first, n_utts, d_scores, d_best, d_path, nullptr);
+    if (e == hipSuccess) rc = jdsp_hmm_viterbi_dev(h, d_feats, n_frames, d_first, n_utts, d_scores, d_best, d_path, d_trellis);
     if (e == hipSuccess && rc == JDSP_OK && scores_host)
         e = hipMemcpyAsync(scores_host, d_scores, sz_scores, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess && rc == JDSP_OK && best_host)
         e = hipMemcpyAsync(best_host, d_best, (size_t)n_utts * sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess && rc == JDSP_OK && path_host && n_frames > 0)
         e = hipMemcpyAsync(path_host, d_path, (size_t)h->n_models * n_frames * sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess && rc == JDSP_OK && trellis_host && n_frames > 0)
+        e = hipMemcpyAsync(trellis_host, d_trellis, (size_t)h->n_models * 6 * n_frames * sizeof(double), hipMemcpyDeviceToHost,
+                           ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     else (void)hipStreamSynchronize(ctx->stream);
     (void)hipFree(d_feats); (void)hipFree(d_first); (void)hipFree(d_scores); (void)hipFree(d_best); (void)hipFree(d_path);
+    (void)hipFree(d_trellis);
     if (rc) return rc;
     if (e != hipSuccess) return fail(ctx, JDSP_EHIP, "jdsp_hmm_viterbi", e);
     return JDSP_OK;

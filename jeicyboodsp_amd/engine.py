@@ -465,8 +465,10 @@ class Hmm(_Child):
         scores = np.empty((n_utts, self.n_models), np.float64)
         best = np.empty((n_utts,), np.int32)
         path = np.zeros((self.n_models, n_frames), np.int32) if want_path else None
-        self.eng._ck(L.jdsp_hmm_viterbi(self._h, _vp(feats), _vp(utt_first), n_utts, _vp(scores), _vp(best), _vp(path)))
-        return scores, best, path
+        trellis = np.zeros((self.n_models, 6, n_frames), np.float64) if want_trellis else None
+        self.eng._ck(L.jdsp_hmm_viterbi(self._h, _vp(feats), _vp(utt_first), n_utts, _vp(scores), _vp(best), _vp(path),
+                                        _vp(trellis)))
+        return (scores, best, path, trellis) if want_trellis else (scores, best, path)
 
 
 class FastConv:

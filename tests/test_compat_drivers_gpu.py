@@ -167,3 +167,80 @@ def test_driver_mvdr_and_pitch1(tmp_path, oracle):
     assert lags.shape == o_arg.shape
     at_ours = o_ac[np.arange(len(lags)), lags]
     assert np.all((lags == o_arg) | (o_max - at_ours <= 1e-5 * (o_ac[:, 0] + 1)))
+
+
+def _write_mfc_lists(tmp_path, utterances_per_list):
+    """The reference's two-level list format (GMMTest:80-95): a file naming class list files, each naming .mfc files."""
+    names, flat = [], []
+    for c, utts in enumerate(utterances_per_list):
+        lst = tmp_path / f"class{c}.txt"
+        paths = []
+        for k, x in enumerate(utts):
+            f = tmp_path / f"c{c}_u{k}.mfc"
+            np.ascontiguousarray(x, np.float64).tofile(f)
+            paths.append(str(f))
+            flat.append((c, x))
+        lst.write_text("\n".join(paths))                                 # no trailing newline, see drivers.cpp
+        names.append(str(lst))
+    top = tmp_path / "test_list.txt"
+    top.write_text("\n".join(names))
+    return top, flat
+
+
+def _run_out(prog, *args, env=None):
+    e = dict(os.environ)
+    e.update(env or {})
+    return subprocess.run([os.path.join(COMPAT, prog)] + [str(a) for a in args], check=True, env=e,
+                          stdout=subprocess.PIPE, timeout=300).stdout.decode()
+
+
+def test_driver_gmmtest_and_compat_recognition(tmp_path, oracle):
+    import gmm_cases as gc
+    classes = gc.gmm_records(41, 25)
+    classes.tofile(tmp_path / "params.bin")
+    utts = [[gc.vectors(50 + 3 * c + k, 5 + 7 * k + c) for k in range(1 + c % 2)] for c in range(25)]
+    top, flat = _write_mfc_lists(tmp_path, utts)
+    out = _run_out("jdsp_gmmtest", top, tmp_path / "params.bin").splitlines()
+    lines = [ln for ln in out if "class probability" in ln or "-th result" in ln]
+    assert len(lines) == len(flat) * 26
+    for u, (c, x) in enumerate(flat):
+        want, arg = oracle.gmm_classify(x, classes)
+        blk = lines[26 * u:26 * (u + 1)]
+        for k in range(25):
+            assert blk[k] == " %d-th class probability %f " % (k + 1, want[k])      # GMMTest:125
+        assert blk[25] == " %d -th result %d " % (c + 1, arg + 1)                    # GMMTest:127
+    # per-call compat function, driven like main()'s class loop
+    x = flat[3][1]
+    x.tofile(tmp_path / "one.mfc")
+    run("compat_selftest", "gmm", tmp_path / "one.mfc", tmp_path / "gmm.bin", tmp_path / "params.bin")
+    got = np.fromfile(tmp_path / "gmm.bin", np.float64)
+    want, arg = oracle.gmm_classify(x, classes)
+    assert np.allclose(got[:25], want, rtol=1e-12, atol=0) and int(got[25]) == arg
+
+
+def test_driver_viterbi_and_compat_hmmrecognition(tmp_path, oracle):
+    import gmm_cases as gc
+    model = gc.hmm_records_finite(42, 1)
+    model.tofile(tmp_path / "hmm.bin")
+    utts = [[gc.vectors_near(60 + k, 4 + 5 * k, model["gMMParam"][0, k % 6]) for k in range(3)]]
+    top, flat = _write_mfc_lists(tmp_path, utts)
+    out = _run_out("jdsp_viterbi", top, tmp_path / "hmm.bin").splitlines()
+    pos = 2                                                                        # the two "-th path" lines
+    for c, x in flat:
+        ret, path, tr = oracle.hmm_viterbi(x, model[0])
+        n = len(x)
+        for i in range(n - 1, 0, -1):
+            assert out[pos] == "max accumulated prob %f " % tr[path[i], i]          # Viterbi:222
+            pos += 1
+        assert out[pos] == "decoding result ! "
+        assert out[pos + 1] == "".join("%d ," % s for s in path[:n - 1])
+        assert out[pos + 2] == " 1-th class probability %f " % ret                  # Viterbi:127
+        assert out[pos + 3] == " 1 -th result 1 "                                   # Viterbi:129
+        pos += 4
+    assert pos == len(out)
+    x = flat[2][1]
+    x.tofile(tmp_path / "one.mfc")
+    run("compat_selftest", "hmm", tmp_path / "one.mfc", tmp_path / "hmm_out.bin", tmp_path / "hmm.bin")
+    got = np.fromfile(tmp_path / "hmm_out.bin", np.float64)
+    ret, _, _ = oracle.hmm_viterbi(x, model[0])
+    assert np.allclose(got[0], ret, rtol=1e-12, atol=0)
