@@ -1,7 +1,7 @@
 // gmm_kernels.hip -- GMM scoring and the HMM recursion on device-resident MFCC vectors (gfx950).
 //
 //   gmm_score_kernel     Recognition() + the class arg-max   GMMAlgorithm_Test_Auto_ver2.cpp:113-127,:151-162
-//   gmm_emission_kernel  sum_k alpa[k] probability_k(x)       Viterbi_version1.cpp:183-185,:193-195
+//   gmm_emission_kernel  log sum_k alpa[k] probability_k(x)   Viterbi_version1.cpp:183-186,:193-196
 //   hmm_trellis_kernel   HMMRecognition()                      Viterbi_version1.cpp:157-246
 //
 // Everything is FP64 like the reference (these are a few hundred flops per 96-byte vector: neither HBM nor
@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void gmm_score_kernel(const double *__restrict
     }
 }
 
-// b[f][g] for every frame f and every state GMM g (n_g = models * 6); 64 frames x one g per wave.
+// log b[f][g] for every frame f and every state GMM g (n_g = models * 6); 64 frames x one g per wave.
 __global__ __launch_bounds__(64) void gmm_emission_kernel(const double *__restrict__ feats, long n_frames,
                                                           const double *__restrict__ gmm, int n_g,
                                                           double *__restrict__ b)
@@ -110,69 +110,78 @@ __global__ __launch_bounds__(64) void gmm_emission_kernel(const double *__restri
     if (f >= n_frames) return;
     double x[12];
     load_vector(feats, f, x);
-    b[f * n_g + gi] = gmm_mixture(x, gmm + (size_t)gi * kGmmRecord);
+    b[f * n_g + gi] = log(gmm_mixture(x, gmm + (size_t)gi * kGmmRecord));                          // Viterbi:186,:196
 }
 
-// One thread per utterance, models in turn: the six-state recursion as the reference writes it
-// (log of the previous accumulated log probability, :196; first-u assignment then `<`, :198-204),
-// the per-frame arg-max state (:212-221) as the "decoding result", the frame-1 maximum as the score,
-// and the model arg-max of :119-126.
-__global__ __launch_bounds__(64) void hmm_trellis_kernel(const double *__restrict__ b,
+// Eight lanes per utterance (six used, one per state m), models in turn: the six-state recursion as the
+// reference writes it (log of the previous accumulated log probability, :196; first-u assignment then `<`,
+// :198-204), the per-frame arg-max state (:212-221) as the "decoding result", the frame-1 maximum as the
+// score, and the model arg-max of :119-126.  `lb` holds log(b) from gmm_emission_kernel, so the serial chain
+// per vector is one log(), six exchanges within the group and the compare ladder.
+__global__ __launch_bounds__(64) void hmm_trellis_kernel(const double *__restrict__ lb,
                                                          const long long *__restrict__ utt_first, long n_utts,
                                                          long n_frames_total, const double *__restrict__ log_trans,
                                                          int n_models, double log_init, double *__restrict__ scores,
                                                          int *__restrict__ best, int *__restrict__ path,
                                                          double *__restrict__ trellis)
 {
-    const long u = (long)blockIdx.x * 64 + threadIdx.x;
-    if (u >= n_utts) return;
+    const int lane = threadIdx.x;
+    const int base = lane & ~7, m = (lane & 7) < 6 ? (lane & 7) : 5;   // lanes 6, 7 of a group shadow state 5
+    const bool writer = (lane & 7) < 6, leader = (lane & 7) == 0;
+    long u = (long)blockIdx.x * 8 + (lane >> 3);
+    const bool live = u < n_utts;
+    if (!live) u = n_utts - 1;                                          // keep the whole wave in the exchanges
     const long first = clamp_offset(utt_first[u], n_frames_total), last = clamp_offset(utt_first[u + 1], n_frames_total);
+    // every group of the wave walks as many vectors as the longest one (exchanges are wave-wide)
+    long len = last - first;
+#pragma unroll
+    for (int o = 8; o < 64; o <<= 1) {
+        const long other = __shfl_xor(len, o, 64);
+        len = other > len ? other : len;
+    }
     const int n_g = n_models * 6;
     double mx_model = 0.0;
     int arg_model = 0;
     for (int mdl = 0; mdl < n_models; mdl++) {
-        const double *lt = log_trans + 36 * mdl;
-        double prev[6], cur[6];
-        double ret = 0.0;
-        for (long f = first; f < last; f++) {
-            const double *bf = b + f * n_g + 6 * mdl;
-            int arg = 0;
-            if (f == first) {
+        double lt[6];
 #pragma unroll
-                for (int m = 0; m < 6; m++) cur[m] = log(bf[m]) + log_init;                         // :186
+        for (int q = 0; q < 6; q++) lt[q] = log_trans[36 * mdl + 6 * q + m];                        // into state m
+        double cur = 0.0, ret = 0.0;
+        for (long i = 0; i < len; i++) {
+            const long f = first + i;
+            const bool on = f < last;
+            const double lbm = on ? lb[f * n_g + 6 * mdl + m] : 0.0;
+            const double lp = log(cur);                                                             // :196
+            double nxt;
+            if (i == 0) {
+                nxt = lbm + log_init;                                                               // :186
             } else {
-                double lp[6];
+                nxt = (__shfl(lp, base, 64) + lt[0]) + lbm;                                         // u = 0
 #pragma unroll
-                for (int q = 0; q < 6; q++) lp[q] = log(prev[q]);
-#pragma unroll
-                for (int m = 0; m < 6; m++) {
-                    const double lb = log(bf[m]);
-                    double v = (lp[0] + lt[m]) + lb;                                                // :196, u = 0
-#pragma unroll
-                    for (int q = 1; q < 6; q++) {
-                        const double t = (lp[q] + lt[6 * q + m]) + lb;
-                        if (v < t) v = t;                                                           // :201
-                    }
-                    cur[m] = v;
+                for (int q = 1; q < 6; q++) {
+                    const double t = (__shfl(lp, base + q, 64) + lt[q]) + lbm;
+                    if (nxt < t) nxt = t;                                                           // :201
                 }
-                double mx = cur[0];
-#pragma unroll
-                for (int m = 1; m < 6; m++)
-                    if (cur[m] > mx) { mx = cur[m]; arg = m; }                                      // :217
-                if (f == first + 1) ret = mx;
             }
-            if (path) path[(size_t)mdl * n_frames_total + f] = arg;
+            double mx = __shfl(nxt, base, 64);
+            int arg = 0;
 #pragma unroll
-            for (int m = 0; m < 6; m++) {
-                if (trellis) trellis[((size_t)mdl * 6 + m) * n_frames_total + f] = cur[m];
-                prev[m] = cur[m];
+            for (int q = 1; q < 6; q++) {
+                const double c = __shfl(nxt, base + q, 64);
+                if (c > mx) { mx = c; arg = q; }                                                    // :217
+            }
+            if (on) {
+                cur = nxt;
+                if (i == 1) ret = mx;
+                if (live && leader && path) path[(size_t)mdl * n_frames_total + f] = i == 0 ? 0 : arg;
+                if (live && writer && trellis) trellis[((size_t)mdl * 6 + m) * n_frames_total + f] = nxt;
             }
         }
-        if (scores) scores[u * n_models + mdl] = ret;
+        if (live && leader && scores) scores[u * n_models + mdl] = ret;
         if (mdl == 0) { mx_model = ret; arg_model = 0; }
         else if (mx_model < ret) { mx_model = ret; arg_model = mdl; }                               // Viterbi:119-126
     }
-    if (best) best[u] = arg_model;
+    if (live && leader && best) best[u] = arg_model;
 }
 
 int launch_gmm_score(hipStream_t stream, const double *feats, long n_frames, const long long *utt_first, long n_utts,
@@ -194,7 +203,7 @@ int launch_hmm_viterbi(hipStream_t stream, const double *feats, long n_frames, c
                            dim3(64), 0, stream, feats, n_frames, gmm, n_models * 6, b);
         if (hipGetLastError() != hipSuccess) return -1;
     }
-    hipLaunchKernelGGL(hmm_trellis_kernel, dim3((unsigned)((n_utts + 63) / 64)), dim3(64), 0, stream, b, utt_first,
+    hipLaunchKernelGGL(hmm_trellis_kernel, dim3((unsigned)((n_utts + 7) / 8)), dim3(64), 0, stream, b, utt_first,
                        n_utts, n_frames, log_trans, n_models, log_init, scores, best, path, trellis);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }

@@ -127,3 +127,18 @@ def fastconv_sharded(conv, pcm, n_blocks, rank, world):
     # position first_in >= hist_blocks: every fed block emits; the first hist_blocks of them saw a silent history
     drop = out.shape[1] - cnt * conv.block
     return out[:, drop:]
+
+
+def utterance_batch_shard(utt_first, rank, world):
+    """GMM scoring / HMM recursion over a batch of utterances (jdsp_gmm_score_dev, jdsp_hmm_viterbi_dev):
+    whole utterances per rank, balanced by vector count; no halo, no collective on the data path.
+    utt_first: the n_utts + 1 offsets of the whole batch (host sequence).  Returns
+    (first_utt, n_utt, vec_lo, vec_hi, local_first): this rank scores vectors [vec_lo, vec_hi) with the
+    offsets local_first (rebased to 0); its rows of the [n_utts, n_classes] result are
+    [first_utt, first_utt + n_utt).  all_gather_rows() assembles the full table if every rank wants it."""
+    lens = [int(utt_first[u + 1]) - int(utt_first[u]) for u in range(len(utt_first) - 1)]
+    first_utt, n_utt = utterance_shard(lens, rank, world)
+    lo = int(utt_first[first_utt])
+    hi = int(utt_first[first_utt + n_utt])
+    local_first = [int(utt_first[first_utt + k]) - lo for k in range(n_utt + 1)]
+    return first_utt, n_utt, lo, hi, local_first

@@ -164,6 +164,33 @@ def test_offsets_past_the_end_are_clamped_on_the_device(eng, oracle):
     g.close()
 
 
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_utterance_sharded_scoring_equals_the_single_gpu_batch(eng, world):
+    """§8(e) for rank 4: whole utterances per rank, no collective; simulated ranks on one GPU."""
+    from jeicyboodsp_amd import sharding
+    lens = [5, 300, 1, 64, 77, 0, 130, 9, 256, 31, 2]
+    first = gc.offsets(lens)
+    x = gc.vectors(26, int(first[-1]))
+    classes = gc.gmm_records(27, 25)
+    models = gc.hmm_records_finite(28, 2)
+    g, h = eng.gmm(classes), eng.hmm(models)
+    want_s, want_b = g.score(x, first)
+    want_hs, want_hb, want_hp = h.viterbi(x, first)
+    rows_s, rows_b, rows_hs, rows_hb, cols_hp = [], [], [], [], []
+    for r in range(world):
+        u0, n, lo, hi, local = sharding.utterance_batch_shard(first, r, world)
+        s, b = g.score(x[lo:hi], np.asarray(local, np.int64))
+        hs, hb, hp = h.viterbi(x[lo:hi], np.asarray(local, np.int64))
+        rows_s.append(s); rows_b.append(b); rows_hs.append(hs); rows_hb.append(hb); cols_hp.append(hp)
+    assert np.array_equal(np.concatenate(rows_s), want_s, equal_nan=True)
+    assert np.array_equal(np.concatenate(rows_b), want_b)
+    assert np.array_equal(np.concatenate(rows_hs), want_hs, equal_nan=True)
+    assert np.array_equal(np.concatenate(rows_hb), want_hb)
+    assert np.array_equal(np.concatenate(cols_hp, axis=1), want_hp)
+    g.close()
+    h.close()
+
+
 def test_gmm_hmm_errors(eng):
     import jeicyboodsp_amd
     with pytest.raises(jeicyboodsp_amd.JdspError):

@@ -102,3 +102,18 @@ def test_two_rank_gloo_sharded_equals_single(n_frames):
     mp.spawn(_worker, args=(2, port, n_frames, ret), nprocs=2, join=True)
     assert ret["stft_equal"] is True
     assert ret["conv_err"] < 1e-9
+
+
+def test_utterance_batch_shard_covers_every_utterance_once():
+    rng = np.random.default_rng(5)
+    lens = rng.integers(0, 400, 97).tolist()
+    first = np.concatenate([[0], np.cumsum(lens)])
+    for world in (1, 2, 3, 8):
+        seen, vecs = [], 0
+        for r in range(world):
+            u0, n, lo, hi, local = sharding.utterance_batch_shard(first, r, world)
+            seen += list(range(u0, u0 + n))
+            assert local[0] == 0 and local[-1] == hi - lo and len(local) == n + 1
+            assert [local[k + 1] - local[k] for k in range(n)] == lens[u0:u0 + n]
+            vecs += hi - lo
+        assert seen == list(range(97)) and vecs == first[-1]

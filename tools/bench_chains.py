@@ -138,6 +138,31 @@ def main():
                "10,000 ragged utterances, %d frames; an 8-way utterance split is balanced to %.2f%%"
                % (len(starts), 100.0 * (max(loads) - min(loads)) / max(loads)))
         m.close()
+    if on("gmm"):
+        # the 10,000-utterance batch's MFCC vectors (12 cepstra, native MFCC configuration
+        # framing is irrelevant here) scored where they lie: 25 classes (GMMTest:26) / one 6-state model (Viterbi:26-28)
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import gmm_cases as gc
+        fpu = rng.integers(98, 598, 10000)
+        first = np.concatenate([[0], np.cumsum(fpu)]).astype(np.int64)
+        nvec = int(first[-1])
+        feats_h = rng.normal(0.0, 3.0, (nvec, 12))
+        feats, first_d = torch.from_numpy(feats_h).cuda(), torch.from_numpy(first).cuda()
+        classes = gc.gmm_records(1, 25)
+        g = eng.gmm(classes)
+        ms = timed(lambda: g.score(feats, first_d), max(a.iters // 8, 3))
+        # per vector and class: 4 mixtures x (48 MAC + 4 x ~8 flops + 4 exp) + 1 log ~ 550 FP64 flops
+        report("gmm_score_25_classes_10k_utterances", ms, nvec, "vectors", 96, 25 * 550,
+               "FP64; %d vectors in 10,000 utterances against 25 four-mixture GMMs; flops are FP64" % nvec,
+               cpu=cpu_rate(lambda: orc.gmm_classify(feats_h[:2000], classes), 2000))
+        g.close()
+        models = gc.hmm_records(2, 1)
+        h = eng.hmm(models)
+        ms = timed(lambda: h.viterbi(feats, first_d, want_path=True), max(a.iters // 8, 3))
+        report("hmm_recursion_6_states_10k_utterances", ms, nvec, "vectors", 96 + 4, 6 * 550,
+               "FP64; emission kernel (vector-parallel) + one thread per utterance for the recursion",
+               cpu=cpu_rate(lambda: orc.hmm_viterbi(feats_h[:20000], models[0]), 20000))
+        h.close()
     if on("fastconv"):
         nb = 4096
         taps = rng.normal(size=7169) * 0.01
