@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libjdsp.so")
+# JDSP_LIB: a differently built libjdsp.so (tools/ A/B timing of build-time variants); default: the in-tree build
+LIB_PATH = os.environ.get("JDSP_LIB") or os.path.join(_HERE, "libjdsp.so")
 
 OK, EINVAL, EHIP, ENOMEM, ENODEV = 0, -1, -2, -3, -4
 
