@@ -101,8 +101,10 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--frames", type=int, default=FRAMES_PER_GPU, help="frames per GPU per step")
-    ap.add_argument("--gather", action="store_true", help="also time an RCCL all_gather of the spectra (reported separately)")
-    ap.add_argument("--no-gather", action="store_true", help="skip the (separately reported) output all_gather at N > 1")
+    ap.add_argument("--gather", action="store_true",
+                    help="also time an RCCL all_gather of the spectra after the timed region (reported separately; the path "
+                         "itself has no exchange step, so this is off unless asked for)")
+    ap.add_argument("--no-gather", action="store_true", help="accepted for compatibility: the gather is opt-in")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="time eager launches instead of one hipGraph replay of the K steps")
     args = ap.parse_args()
@@ -173,9 +175,9 @@ def main():
 
     # The only collective of the path: gathering the spectra (RCCL all_gather over xGMI).  Timed
     # AFTER and OUTSIDE the timed region, reported separately, never part of `value` (SURVEY §5:
-    # at 8 GPUs it costs far more than the transform).  On by default when there is more than one rank.
+    # at 8 GPUs it costs far more than the transform).  Only with --gather.
     gather_ms = None
-    if dist is not None and (args.gather or (world > 1 and not args.no_gather)):
+    if dist is not None and args.gather and not args.no_gather:
         try:
             from jeicyboodsp_amd import sharding
             sharding.all_gather_rows(spec, [B] * world, dist)
