@@ -215,7 +215,9 @@ int jdsp_fastconv_process(jdsp_fastconv *h, const int16_t *pcm_host, long n_bloc
  * Frame b = [block b-1, block b] with no window; block -1 is prev_block (NULL: zeros, the
  * reference's initial keep buffer, :74).  arg[b] = the lag the reference prints as
  * "Estimation arg" (:109; pitch = 16000/arg), rmax[b] = the autocorrelation there;
- * autocorr (may be NULL) = r[0..511] per block (:95-97).  pcm must be 16-byte aligned. */
+ * autocorr (may be NULL) = r[0..511] per block (:95-97).  pcm must be 16-byte aligned.
+ * AnalysisAdditiveWhiteGaussianNoise.cpp:98-133 (the analysis half of that program) is this same chain
+ * without the arg-max: its dAutoCorrelation (:122-124) is the autocorr output here. */
 int jdsp_pitch_autocorr_dev(jdsp_ctx *ctx, const int16_t *pcm_dev, long n_blocks, const int16_t *prev_block_dev,
                             int32_t *arg_dev, float *rmax_dev, float *autocorr_dev);
 int jdsp_pitch_autocorr(jdsp_ctx *ctx, const int16_t *pcm_host, long n_blocks, const int16_t *prev_block_host,

@@ -1,6 +1,6 @@
 // compat_selftest.cpp -- drives the reference-signature functions exactly the way the
 // reference main()s do (one block per call) and dumps what they return, for tests/ to compare
-// with the CPU checker.  usage: compat_selftest <ss|wf|conv|mfcc|pitch|fft|gmm|hmm> in.raw out.bin [taps.f64 | params.bin]
+// with the CPU checker.  usage: compat_selftest <ss|wf|conv|mfcc|pitch|awgn|fft|gmm|hmm> in.raw out.bin [taps.f64 | params.bin]
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -62,6 +62,11 @@ int main(int argc, char **argv)
             CalcPitch(&pcm[b], 512);
             int a = JeicybooLastPitchArg();
             fwrite(&a, 4, 1, out);
+        }
+    } else if (!strcmp(what, "awgn")) {
+        for (size_t b = 0; b + 512 <= pcm.size(); b += 512) {
+            AnalysisAdditiveWhiteGaussianNoise(&pcm[b], 512);
+            fwrite(JeicybooLastAutoCorrelation(), 8, 512, out);
         }
     } else if (!strcmp(what, "gmm") || !strcmp(what, "hmm")) {
         // in.raw = raw double[12] vectors of one utterance (an .mfc file), argv[4] = parameter records

@@ -205,6 +205,20 @@ void CalcPitch(short *in, int n)
 int JeicybooLastPitchArg(void) { return g_pitch_arg; }
 double JeicybooLastPitchMax(void) { return g_pitch_max; }
 
+// ---- AnalysisAdditiveWhiteGaussianNoise.cpp:98-133 --------------------------------------------
+static short g_awgn_keep[512];                     // rgssKeepBuffer (:103)
+static double g_awgn_autocorr[512];
+void AnalysisAdditiveWhiteGaussianNoise(short *noise, int n)
+{
+    if (n != 512) { fprintf(stderr, "AnalysisAdditiveWhiteGaussianNoise: iFrameCount must be 512\n"); abort(); }
+    int32_t arg = 0;
+    float rmax = 0, r[512];
+    CK(jdsp_pitch_autocorr(JeicybooContext(), noise, 1, g_awgn_keep, &arg, &rmax, r));
+    for (int i = 0; i < 512; i++) g_awgn_autocorr[i] = r[i];                                    // :122-124
+    memcpy(g_awgn_keep, noise, sizeof(g_awgn_keep));                                            // :129
+}
+const double *JeicybooLastAutoCorrelation(void) { return g_awgn_autocorr; }
+
 // ---- GMMAlgorithm_Test_Auto_ver2.cpp / Viterbi_version1.cpp -----------------------------------
 static std::vector<double> gather_rows(double **rows, int n)
 {

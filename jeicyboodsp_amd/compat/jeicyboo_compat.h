@@ -59,6 +59,14 @@ void CalcPitch(short *psInputBuffer, int iFrameCount);                          
 int JeicybooLastPitchArg(void);
 double JeicybooLastPitchMax(void);
 
+// ---- AnalysisAdditiveWhiteGaussianNoise.cpp:37 (the analysis half, :98-133) ------------------
+// Same chain as CalcPitch without the arg-max: frame [previous noise block, block], |X|^2, inverse, /1024.
+// The reference discards dAutoCorrelation (a local, :104); here the last call's 512 lags can be read back.
+// The generation half (time-seeded std::normal_distribution, GetTickCount, :85-96,:136-145) is not part of
+// the spectral path and is not provided.
+void AnalysisAdditiveWhiteGaussianNoise(short *psNoiseBuffer, int iFrameCount);                // :98
+const double *JeicybooLastAutoCorrelation(void);                                                // dAutoCorrelation[512]
+
 // ---- GMMAlgorithm_Test_Auto_ver2.cpp:29-34,:44 / Viterbi_version1.cpp:30-40,:49 -------------
 // The parameter records are the C ABI's (same layout as the reference's structs).  One call scores one
 // utterance against one record; the class loop of main() (GMMTest:113-127) calls Recognition once per

@@ -244,3 +244,17 @@ def test_driver_viterbi_and_compat_hmmrecognition(tmp_path, oracle):
     got = np.fromfile(tmp_path / "hmm_out.bin", np.float64)
     ret, _, _ = oracle.hmm_viterbi(x, model[0])
     assert np.allclose(got[0], ret, rtol=1e-12, atol=0)
+
+
+def test_compat_awgn_analysis_autocorrelation(tmp_path, oracle):
+    """AnalysisAdditiveWhiteGaussianNoise.cpp:98-133: the same FFT -> |X|^2 -> inverse chain as CalcPitch
+    (the oracle's pitch restatement returns the lags), driven with sigma-10 noise blocks like :138."""
+    rng = np.random.default_rng(77)
+    noise = np.clip(np.rint(rng.normal(0.0, 10.0, 512 * 9)), -32768, 32767).astype(np.int16)
+    noise.tofile(tmp_path / "n.raw")
+    run("compat_selftest", "awgn", tmp_path / "n.raw", tmp_path / "ac.bin")
+    got = np.fromfile(tmp_path / "ac.bin", np.float64).reshape(9, 512)
+    _, _, want = oracle.pitch_stream(noise)
+    assert np.abs(got - want).max() <= 1e-5 * np.abs(want[:, 0]).max()
+    # white noise: R(0) ~ energy of the two blocks in the frame, other lags far below it (the program's point)
+    assert np.all(np.abs(got[1:, 1:]).max(axis=1) < 0.2 * got[1:, 0])
