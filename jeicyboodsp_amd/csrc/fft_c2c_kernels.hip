@@ -66,6 +66,111 @@ __global__ __launch_bounds__(256) void fft_process_f64_kernel(const double2 *__r
     for (int k = threadIdx.x; k < n_fft; k += blockDim.x) dst[k] = x[k];
 }
 
+// ---- n_fft = 512 (the reference's native BLOCK_LEN, FFT:16): one transform per wavefront -----------------
+// Same decomposition as wave_fft512.h (three in-register radix-8 passes, two wave-private LDS exchanges,
+// "lane + 64 r" layout in and out) in double precision: 8 KB in, 8 KB out per transform, all loads and
+// stores 16 B per lane and coalesced, no workgroup barrier.  The DFT is the same; only the order of the
+// additions differs from the reference's radix-2 DIT (1e-16-level rounding).  Twiddles are read from the
+// c2c table: w_512^j = tw[j & 255], negated when j & 256.
+struct cd {
+    double x, y;
+};
+__device__ __forceinline__ cd cd_add(cd a, cd b) { return {a.x + b.x, a.y + b.y}; }
+__device__ __forceinline__ cd cd_sub(cd a, cd b) { return {a.x - b.x, a.y - b.y}; }
+__device__ __forceinline__ cd cd_mul(cd a, cd w) { return {a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x}; }
+template <bool INV> __device__ __forceinline__ cd cd_rot90(cd a) { return INV ? cd{-a.y, a.x} : cd{a.y, -a.x}; }
+template <bool INV> __device__ __forceinline__ cd cd_rot45(cd a)
+{
+    const double c = 0.70710678118654752440;
+    return INV ? cd{c * (a.x - a.y), c * (a.x + a.y)} : cd{c * (a.x + a.y), c * (a.y - a.x)};
+}
+template <bool INV> __device__ __forceinline__ cd cd_rot135(cd a)
+{
+    const double c = 0.70710678118654752440;
+    return INV ? cd{-c * (a.x + a.y), c * (a.x - a.y)} : cd{c * (a.y - a.x), -c * (a.x + a.y)};
+}
+template <bool INV> __device__ __forceinline__ void cd_dft8(cd (&v)[8])
+{
+    cd a0 = cd_add(v[0], v[4]), a4 = cd_sub(v[0], v[4]);
+    cd a1 = cd_add(v[1], v[5]), a5 = cd_rot45<INV>(cd_sub(v[1], v[5]));
+    cd a2 = cd_add(v[2], v[6]), a6 = cd_rot90<INV>(cd_sub(v[2], v[6]));
+    cd a3 = cd_add(v[3], v[7]), a7 = cd_rot135<INV>(cd_sub(v[3], v[7]));
+    cd b0 = cd_add(a0, a2), b2 = cd_sub(a0, a2);
+    cd b1 = cd_add(a1, a3), b3 = cd_rot90<INV>(cd_sub(a1, a3));
+    cd b4 = cd_add(a4, a6), b6 = cd_sub(a4, a6);
+    cd b5 = cd_add(a5, a7), b7 = cd_rot90<INV>(cd_sub(a5, a7));
+    v[0] = cd_add(b0, b1); v[4] = cd_sub(b0, b1);
+    v[2] = cd_add(b2, b3); v[6] = cd_sub(b2, b3);
+    v[1] = cd_add(b4, b5); v[5] = cd_sub(b4, b5);
+    v[3] = cd_add(b6, b7); v[7] = cd_sub(b6, b7);
+}
+template <bool INV> __device__ __forceinline__ cd w512(const double2 *__restrict__ tw, int j)
+{
+    const double2 t = tw[j & 255];
+    const double s = (j & 256) ? -1.0 : 1.0;
+    return {s * t.x, INV ? -s * t.y : s * t.y};
+}
+__device__ __forceinline__ void lds_fence_wave()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+constexpr int kFft512Lds = 8 * 73;                        // cd elements per wave (9,344 B)
+
+template <bool INV>
+__global__ __launch_bounds__(64) void fft512_f64_kernel(const double2 *__restrict__ in, double2 *__restrict__ out, long batch,
+                                                        const double2 *__restrict__ tw)
+{
+    __shared__ __attribute__((aligned(16))) cd lds[kFft512Lds];
+    const int lane = threadIdx.x;
+    const long per_xcd = (gridDim.x + 7) >> 3;            // XCD-aware order: neighbouring transforms share an XCD's L2
+    const long t = (long)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (t >= batch) return;
+    const double2 *src = in + t * 512 + lane;
+    cd v[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const double2 q = src[64 * r];
+        v[r] = {q.x, q.y};
+    }
+    cd_dft8<INV>(v);
+#pragma unroll
+    for (int k = 1; k < 8; k++) v[k] = cd_mul(v[k], w512<INV>(tw, lane * k));
+#pragma unroll
+    for (int k = 0; k < 8; k++) lds[k * 72 + lane] = v[k];
+    lds_fence_wave();
+    {
+        const int base = (lane >> 3) * 72 + (lane & 7);
+#pragma unroll
+        for (int a = 0; a < 8; a++) v[a] = lds[base + 8 * a];
+    }
+    lds_fence_wave();
+    cd_dft8<INV>(v);
+#pragma unroll
+    for (int c = 1; c < 8; c++) v[c] = cd_mul(v[c], w512<INV>(tw, 8 * (lane & 7) * c));
+    {
+        const int base = (lane >> 3) * 73 + (lane & 7);
+#pragma unroll
+        for (int c = 0; c < 8; c++) lds[base + 8 * c] = v[c];
+    }
+    lds_fence_wave();
+    {
+        const int base = (lane & 7) * 73 + (lane >> 3) * 8;
+#pragma unroll
+        for (int b = 0; b < 8; b++) v[b] = lds[base + b];
+    }
+    cd_dft8<INV>(v);
+    typedef double f64x2 __attribute__((ext_vector_type(2)));
+    f64x2 *dst = reinterpret_cast<f64x2 *>(out + t * 512 + lane);
+#pragma unroll
+    for (int d = 0; d < 8; d++) {
+        f64x2 q = {v[d].x, v[d].y};
+        __builtin_nontemporal_store(q, dst + 64 * d);
+    }
+}
+
 int launch_bitrev_table(hipStream_t stream, short *table_dev, int n_fft, int bits)
 {
     hipLaunchKernelGGL(bitrev_table_kernel, dim3((n_fft + 255) / 256), dim3(256), 0, stream, table_dev, n_fft, bits);
@@ -76,6 +181,12 @@ int launch_fft_process_f64(hipStream_t stream, const double2 *in, double2 *out, 
                            int forward, const double2 *tw)
 {
     if (batch <= 0) return 0;
+    if (n_fft == 512 && (((uintptr_t)in | (uintptr_t)out) & 15u) == 0) {
+        const long grid = (batch + 7) / 8 * 8;
+        if (forward) hipLaunchKernelGGL(fft512_f64_kernel<false>, dim3((unsigned)grid), dim3(64), 0, stream, in, out, batch, tw);
+        else hipLaunchKernelGGL(fft512_f64_kernel<true>, dim3((unsigned)grid), dim3(64), 0, stream, in, out, batch, tw);
+        return hipGetLastError() == hipSuccess ? 0 : -1;
+    }
     const size_t lds = sizeof(double2) * (size_t)n_fft;
     int threads = n_fft / 2 < 256 ? (n_fft / 2 < 64 ? 64 : n_fft / 2) : 256;
     if (lds > 64 * 1024) {
