@@ -226,8 +226,7 @@ __device__ __forceinline__ void forward_to_lds(const unsigned int *raw, const Fr
         v[r] = make_float2(s.x * t.win[r].x, s.y * t.win[r].y);
     }
     wave_fft512<false>(v, lds, lane, t.tw);
-#pragma unroll
-    for (int d = 0; d < 8; d++) lds[lane + 64 * d] = v[d];
+    store_natural_image(lds, lane, v);
     wave_lds_fence();
 }
 
@@ -237,8 +236,8 @@ __device__ __forceinline__ void mag_store_j(const float2 *lds, int lane, const f
 {
     const int m = 128 * J + 2 * lane;
     const float4 zz = *reinterpret_cast<const float4 *>(&lds[m]);
-    const float2 zr0 = lds[(512 - m) & 511];
-    const float2 zr1 = lds[511 - m];
+    float2 zr0, zr1;
+    load_mirror_pair(lds, m, zr0, zr1);
     float2 lo0, hi0, lo1, hi1;
     split_fwd<J>(make_float2(zz.x, zz.y), zr0, wsp[0], lo0, hi0);
     split_fwd<J>(make_float2(zz.z, zz.w), zr1, wsp[1], lo1, hi1);
@@ -332,8 +331,8 @@ __device__ __forceinline__ void gain_presplit_j(const float2 *lds, float2 *zout,
 {
     const int m = 128 * J + 2 * lane;
     const float4 zz = *reinterpret_cast<const float4 *>(&lds[m]);
-    const float2 zr0 = lds[(512 - m) & 511];
-    const float2 zr1 = lds[511 - m];
+    float2 zr0, zr1;
+    load_mirror_pair(lds, m, zr0, zr1);
     const float2 nlo = *reinterpret_cast<const float2 *>(noise + m);
     const float2 nhi = *reinterpret_cast<const float2 *>(noise + m + 512);
     float2 lo0, hi0, lo1, hi1;

@@ -48,8 +48,8 @@ __device__ __forceinline__ void conv_mul_presplit_j(const float2 *lds, float2 *z
 {
     const int m = 128 * J + 2 * lane;
     const float4 zz = *reinterpret_cast<const float4 *>(&lds[m]);
-    const float2 zr0 = lds[(512 - m) & 511];
-    const float2 zr1 = lds[511 - m];
+    float2 zr0, zr1;
+    load_mirror_pair(lds, m, zr0, zr1);
     float2 lo0, hi0, lo1, hi1;
     split_fwd<J>(make_float2(zz.x, zz.y), zr0, wsp[0], lo0, hi0);
     split_fwd<J>(make_float2(zz.z, zz.w), zr1, wsp[1], lo1, hi1);
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(64) void fastconv1024_kernel(ConvStream s, long n_o
                                                           float *__restrict__ precast, long plane)
 {
     __shared__ __attribute__((aligned(16))) float2 lds[kWaveLdsComplex];
-    __shared__ __attribute__((aligned(16))) float2 spec[512];
+    __shared__ __attribute__((aligned(16))) float2 spec[520];       // natural-order image + Z[512]
     const int lane = threadIdx.x;
     const long e = blockIdx.x;
     if (e >= n_out_blocks) return;
@@ -90,8 +90,7 @@ __global__ __launch_bounds__(64) void fastconv1024_kernel(ConvStream s, long n_o
         }
     }
     wave_fft512<false>(v, lds, lane, tw);
-#pragma unroll
-    for (int d = 0; d < 8; d++) spec[lane + 64 * d] = v[d];
+    store_natural_image(spec, lane, v);
     wave_lds_fence();
     for (int f = 0; f < n_filters; f++) {
         const float2 *H = Hall + (size_t)f * 1024;

@@ -60,6 +60,24 @@ __device__ __forceinline__ float2 presplit_inv(float2 ylo, float2 yhi, float2 ws
     return cfnma(one_rot<true>(r), inv_sqrt2_pair(), s);
 }
 
+// The natural-order image of a transform in LDS (element i = Z[i], read by the split steps), with
+// Z[512] = Z[0] in slot 512 so that the mirrored operands need no index mask; the image needs 513 of the
+// scratch's kWaveLdsComplex elements.
+__device__ __forceinline__ void store_natural_image(float2 *img, int lane, const float2 (&v)[8])
+{
+#pragma unroll
+    for (int d = 0; d < 8; d++) img[lane + 64 * d] = v[d];
+    if (lane == 0) img[512] = v[0];
+}
+// Z[512 - m] and Z[511 - m]: two ADJACENT elements, consecutive across lanes -> one conflict-free
+// ds_read2_b64.  (With the index masked to 511 they were two stride-2 reads, 2-way bank conflicts each:
+// SQ_LDS_BANK_CONFLICT was 15-20 % of the LDS cycles of every transform kernel.)
+__device__ __forceinline__ void load_mirror_pair(const float2 *img, int m, float2 &zr0, float2 &zr1)
+{
+    zr1 = img[511 - m];
+    zr0 = img[512 - m];
+}
+
 struct FrameTables {
     WaveTwiddles tw;
     float2 win[8];     // per lane: window pair of samples (2 lane + 128 r, +1), halved

@@ -60,16 +60,15 @@ __global__ __launch_bounds__(64) void mfcc_kernel(const short *__restrict__ pcm,
         }
     }
     wave_fft512<false>(v, lds, lane, tw);
-#pragma unroll
-    for (int d = 0; d < 8; d++) lds[lane + 64 * d] = v[d];
+    store_natural_image(lds, lane, v);
     wave_lds_fence();
     // |X[m]| for m = 128 j + 2 lane + e < 512 (:218-220 computes all 1024, only these are used)
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const int m = 128 * j + 2 * lane;
         const float4 zz = *reinterpret_cast<const float4 *>(&lds[m]);
-        const float2 zr0 = lds[(512 - m) & 511];
-        const float2 zr1 = lds[511 - m];
+        float2 zr0, zr1;
+        load_mirror_pair(lds, m, zr0, zr1);
         float2 lo0, hi0, lo1, hi1;
         if (j == 0) { split_fwd<0>(make_float2(zz.x, zz.y), zr0, wsp0, lo0, hi0); split_fwd<0>(make_float2(zz.z, zz.w), zr1, wsp1, lo1, hi1); }
         if (j == 1) { split_fwd<1>(make_float2(zz.x, zz.y), zr0, wsp0, lo0, hi0); split_fwd<1>(make_float2(zz.z, zz.w), zr1, wsp1, lo1, hi1); }

@@ -28,14 +28,13 @@ __device__ __forceinline__ void spectrum_of(float2 (&v)[8], float2 *lds, int lan
                                             const float2 *wsp, float2 (&lo)[8], float2 (&hi)[8])
 {
     wave_fft512<false>(v, lds, lane, tw);
-#pragma unroll
-    for (int d = 0; d < 8; d++) lds[lane + 64 * d] = v[d];
+    store_natural_image(lds, lane, v);
     wave_lds_fence();
 #define JDSP_SPLIT(J)                                                                          \
     {                                                                                          \
         const int m = 128 * J + 2 * lane;                                                      \
         const float4 zz = *reinterpret_cast<const float4 *>(&lds[m]);                          \
-        const float2 zr0 = lds[(512 - m) & 511], zr1 = lds[511 - m];                           \
+        float2 zr0, zr1; load_mirror_pair(lds, m, zr0, zr1);                           \
         split_fwd<J>(make_float2(zz.x, zz.y), zr0, wsp[0], lo[2 * J], hi[2 * J]);             \
         split_fwd<J>(make_float2(zz.z, zz.w), zr1, wsp[1], lo[2 * J + 1], hi[2 * J + 1]);     \
     }

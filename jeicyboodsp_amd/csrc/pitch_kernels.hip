@@ -11,8 +11,8 @@ __device__ __forceinline__ void power_presplit_j(const float2 *lds, float2 *zout
 {
     const int m = 128 * J + 2 * lane;
     const float4 zz = *reinterpret_cast<const float4 *>(&lds[m]);
-    const float2 zr0 = lds[(512 - m) & 511];
-    const float2 zr1 = lds[511 - m];
+    float2 zr0, zr1;
+    load_mirror_pair(lds, m, zr0, zr1);
     float2 lo0, hi0, lo1, hi1;
     split_fwd<J>(make_float2(zz.x, zz.y), zr0, wsp[0], lo0, hi0);
     split_fwd<J>(make_float2(zz.z, zz.w), zr1, wsp[1], lo1, hi1);
@@ -51,8 +51,7 @@ __global__ __launch_bounds__(64) void pitch_autocorr_kernel(const short *__restr
         v[r] = make_float2(0.5f * s.x, 0.5f * s.y);                     // 0.5: the split's convention (frame_io.h)
     }
     wave_fft512<false>(v, lds, lane, tw);
-#pragma unroll
-    for (int d = 0; d < 8; d++) lds[lane + 64 * d] = v[d];
+    store_natural_image(lds, lane, v);
     wave_lds_fence();
     float2 z[8];
     power_presplit_j<0>(lds, z, lane, wsp);

@@ -59,8 +59,8 @@ __device__ __forceinline__ void split_store_j(const float2 *lds, int lane, const
 {
     const int m = 128 * J + 2 * lane;
     const float4 zz = *reinterpret_cast<const float4 *>(&lds[m]);
-    const float2 zr0 = lds[(512 - m) & 511];
-    const float2 zr1 = lds[511 - m];
+    float2 zr0, zr1;
+    load_mirror_pair(lds, m, zr0, zr1);
     float2 lo0, hi0, lo1, hi1;
     split_fwd<J>(make_float2(zz.x, zz.y), zr0, wsp[0], lo0, hi0);
     split_fwd<J>(make_float2(zz.z, zz.w), zr1, wsp[1], lo1, hi1);
@@ -142,8 +142,7 @@ __global__ __launch_bounds__(64, JDSP_STFT_MINWAVES) void stft1024_hop512_kernel
         wave_fft512<false>(v, lds, lane, t.tw);
 
         // natural-order image of Zh, then the split reads Zh[m] and Zh[512-m]
-#pragma unroll
-        for (int d = 0; d < 8; d++) lds[lane + 64 * d] = v[d];
+        store_natural_image(lds, lane, v);
         wave_lds_fence();
 #if JDSP_STFT_ABLATE == 1   /* timing-only build: transform kept alive, stores never taken */
         if (n_frames < 0)
@@ -168,8 +167,8 @@ __device__ __forceinline__ void split_store_half_j(const float2 *lds, int lane, 
     float2 z0, z1;
     if (ODD) { z0 = lds[m]; z1 = lds[(m + 1) & 511]; }
     else { const float4 zz = *reinterpret_cast<const float4 *>(&lds[m]); z0 = make_float2(zz.x, zz.y); z1 = make_float2(zz.z, zz.w); }
-    const float2 zr0 = lds[(512 - m) & 511];
-    const float2 zr1 = lds[511 - m];
+    float2 zr0, zr1;
+    load_mirror_pair(lds, m, zr0, zr1);
     float2 lo0, hi0, lo1, hi1;
     split_fwd<J>(z0, zr0, w2[0], lo0, hi0);                      // W^m = w_8^J * W^(m - 128 J); m = 512 gives -1
     split_fwd<J>(z1, zr1, w2[1], lo1, hi1);
@@ -233,8 +232,7 @@ __global__ __launch_bounds__(64, JDSP_STFT_MINWAVES) void stft1024_hop512_half_k
             v[r] = make_float2(s.x * t.win[r].x, s.y * t.win[r].y);
         }
         wave_fft512<false>(v, lds, lane, t.tw);
-#pragma unroll
-        for (int d = 0; d < 8; d++) lds[lane + 64 * d] = v[d];
+        store_natural_image(lds, lane, v);
         wave_lds_fence();
         float2 *row = spec + f * pitch;
         if ((i & 1) && (pitch & 1)) {                            // f0 is even (K is): odd row of an odd pitch
@@ -277,8 +275,7 @@ __global__ __launch_bounds__(64) void stft1024_anyhop_kernel(const short *__rest
         for (int r = 0; r < 8; r++)
             v[r] = make_float2((float)src[128 * r] * t.win[r].x, (float)src[128 * r + 1] * t.win[r].y);
         wave_fft512<false>(v, lds, lane, t.tw);
-#pragma unroll
-        for (int d = 0; d < 8; d++) lds[lane + 64 * d] = v[d];
+        store_natural_image(lds, lane, v);
         wave_lds_fence();
         split_and_store(lds, lane, t.wsp, spec + f * 1024);
         wave_lds_fence();
@@ -293,7 +290,7 @@ __device__ __forceinline__ void split_store_even_j(const float2 *lds, int lane, 
 {
     const int m = 128 * J + 2 * lane;
     const float2 zm = lds[m];
-    const float2 zr = lds[(512 - m) & 511];
+    const float2 zr = lds[512 - m];
     float2 lo, hi;
     split_fwd<J>(zm, zr, wsp0, lo, hi);
     __builtin_nontemporal_store(lo.x, &dst[64 * J + lane].x);
@@ -328,8 +325,7 @@ __global__ __launch_bounds__(64) void stft512_kernel(const short *__restrict__ p
 #pragma unroll
         for (int r = 4; r < 8; r++) v[r] = make_float2(0.f, 0.f);
         wave_fft512<false>(v, lds, lane, tw);
-#pragma unroll
-        for (int d = 0; d < 8; d++) lds[lane + 64 * d] = v[d];
+        store_natural_image(lds, lane, v);
         wave_lds_fence();
         float2 *dst = spec + f * 512;
         split_store_even_j<0>(lds, lane, wsp0, dst);
