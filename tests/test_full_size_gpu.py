@@ -100,3 +100,53 @@ def test_mfcc_pitch_fastconv_full_batch_vs_oracle(eng, oracle, golden_dir):
     assert np.abs(pre[0].cpu().numpy() - o_pre).max() < TOL * np.abs(o_pre).max()
     assert np.abs(out[0].cpu().numpy().astype(np.int32) - o_out.astype(np.int32)).max() <= 1
     fc.close()
+
+
+def test_fftprocess_full_batch_properties_and_sample_vs_oracle(eng, oracle):
+    """65,536 FP64 512-point transforms (the one-transform-per-wavefront kernel): inverse(forward(x)) = 512 x,
+    Parseval, linearity, and a sample of transforms against the oracle's FFTProcess."""
+    import torch
+    rng = np.random.default_rng(3)
+    z = torch.from_numpy(rng.normal(size=(B, 512)) + 1j * rng.normal(size=(B, 512))).cuda()
+    Z = eng.fft_process(z)
+    back = eng.fft_process(Z, forward=False)
+    scale = float(z.abs().max())
+    assert float((back / 512 - z).abs().max()) < 1e-12 * scale * 512
+    e_t = (z.abs() ** 2).sum(dim=1)
+    e_f = (Z.abs() ** 2).sum(dim=1) / 512
+    assert float(((e_t - e_f).abs() / e_t).max()) < 1e-12
+    w = torch.from_numpy(rng.normal(size=(B, 512)) + 1j * rng.normal(size=(B, 512))).cuda()
+    lin = eng.fft_process(z + 2.5 * w) - (Z + 2.5 * eng.fft_process(w))
+    assert float(lin.abs().max()) < 1e-11 * scale * 512
+    idx = rng.integers(0, B, 64)
+    want = oracle.fft_process(z[idx].cpu().numpy())
+    got = Z[idx].cpu().numpy()
+    # the reference's twiddles use PI = 3.14159265358 (FFT:15), the device table the true pi: a 1e-11 effect
+    assert np.abs(got - want).max() < 1e-9 * np.abs(want).max()
+
+
+def test_gmm_full_batch_sample_vs_oracle_and_order_invariance(eng, oracle):
+    """The 10,000-utterance batch of tools/bench_chains.py scored against 25 classes: a sample of utterances
+    against the oracle, best == the reference's arg-max rule on the device scores, and reversing the order of
+    the utterances reverses the rows bit for bit (utterances are independent)."""
+    import torch
+    import gmm_cases as gc
+    rng = np.random.default_rng(4)
+    lens = rng.integers(98, 598, 10000)
+    first = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    x = rng.normal(0.0, 3.0, (int(first[-1]), 12))
+    classes = gc.gmm_records(5, 25)
+    g = eng.gmm(classes)
+    scores, best = g.score(torch.from_numpy(x).cuda(), torch.from_numpy(first).cuda())
+    scores, best = scores.cpu().numpy(), best.cpu().numpy()
+    for u in rng.integers(0, 10000, 40):
+        want, arg = oracle.gmm_classify(x[first[u]:first[u + 1]], classes)
+        assert np.all(np.abs(scores[u] - want) <= 1e-12 * np.abs(want))
+        assert best[u] == arg
+    assert np.array_equal(best, scores.argmax(axis=1))               # no ties, no NaN in this batch
+    order = np.arange(10000)[::-1]
+    x_rev = np.concatenate([x[first[u]:first[u + 1]] for u in order])
+    first_rev = np.concatenate([[0], np.cumsum(lens[order])]).astype(np.int64)
+    s_rev, b_rev = g.score(torch.from_numpy(x_rev).cuda(), torch.from_numpy(first_rev).cuda())
+    assert np.array_equal(s_rev.cpu().numpy()[::-1], scores) and np.array_equal(b_rev.cpu().numpy()[::-1], best)
+    g.close()
