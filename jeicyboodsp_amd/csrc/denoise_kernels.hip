@@ -216,6 +216,19 @@ __device__ __forceinline__ u32x4 load_block(const short *__restrict__ pcm, long 
     return zero;
 }
 
+// The same block in the transform's own layout: q[r] = the sample pair (2 lane + 128 r, +1), four coalesced
+// dword loads, nothing to re-lay out.
+__device__ __forceinline__ void load_block_pairs(const short *__restrict__ pcm, long n_blocks,
+                                                 const DenoiseState *__restrict__ st_in, long j, int lane,
+                                                 unsigned int (&q)[4])
+{
+    const unsigned int *src = nullptr;
+    if (j >= 0 && j < n_blocks) src = reinterpret_cast<const unsigned int *>(pcm + j * 512);
+    else if (j == -1) src = reinterpret_cast<const unsigned int *>(st_in->prev);
+#pragma unroll
+    for (int r = 0; r < 4; r++) q[r] = src ? src[lane + 64 * r] : 0u;
+}
+
 // window -> forward transform -> natural-order image of Zh in LDS
 __device__ __forceinline__ void forward_to_lds(const unsigned int *raw, const FrameTables &t, float2 *lds, int lane)
 {
@@ -396,23 +409,22 @@ __global__ __launch_bounds__(64, JDSP_DENOISE_MINWAVES) void denoise_kernel(
     float *__restrict__ precast, DenoiseShard sh)
 {
     __shared__ __attribute__((aligned(16))) float2 lds[kWaveLdsComplex];
-    __shared__ __attribute__((aligned(16))) unsigned int stage[256];
     const int lane = threadIdx.x;
     const long per_xcd = (gridDim.x + 7) >> 3;                // XCD-aware chunk order (speed only)
     const long j0 = ((long)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3)) * K;
     if (j0 >= n_blocks) return;
 
-    u32x4 half[K + 2];                                        // blocks j0-2 .. j0+K-1
+    unsigned int half[K + 2][4];                              // blocks j0-2 .. j0+K-1, pairs 2 lane + 128 r
 #pragma unroll
-    for (int h = 0; h < K + 2; h++) half[h] = load_block(pcm, n_blocks, st_in, j0 - 2 + h, lane);
+    for (int h = 0; h < K + 2; h++) load_block_pairs(pcm, n_blocks, st_in, j0 - 2 + h, lane, half[h]);
     FrameTables t;
     load_frame_tables(t, table, lane);
 
     const long first_emit = sh.emit_from;                     // SS:260-263: calls 1 and 2 emit nothing
     unsigned int raw[8];
     float2 tail[4], y[8];
-    relayout_half(stage, lane, half[0], raw);
-    relayout_half(stage, lane, half[1], raw + 4);
+#pragma unroll
+    for (int r = 0; r < 4; r++) { raw[r] = half[0][r]; raw[r + 4] = half[1][r]; }
     if (j0 == 0) {
         // rgsdOveraped[512..1023] carried over from the previous call
 #pragma unroll
@@ -432,8 +444,7 @@ __global__ __launch_bounds__(64, JDSP_DENOISE_MINWAVES) void denoise_kernel(
         const long j = j0 + i;
         if (j >= n_blocks) break;
 #pragma unroll
-        for (int r = 0; r < 4; r++) raw[r] = raw[r + 4];
-        relayout_half(stage, lane, half[i + 2], raw + 4);
+        for (int r = 0; r < 4; r++) { raw[r] = raw[r + 4]; raw[r + 4] = half[i + 2][r]; }
         if (calls_before + j == 0) {
 #pragma unroll
             for (int d = 0; d < 8; d++) y[d] = make_float2(0.f, 0.f);
@@ -448,19 +459,18 @@ __global__ __launch_bounds__(64, JDSP_DENOISE_MINWAVES) void denoise_kernel(
         }
         if (j >= first_emit && j < sh.emit_to) {
             const long oi = j - first_emit;
+            unsigned int *dst = reinterpret_cast<unsigned int *>(out + oi * 512) + lane;
 #pragma unroll
-            for (int d = 0; d < 4; d++) stage[lane + 64 * d] = cast_i16_bits(o[d].x) | (cast_i16_bits(o[d].y) << 16);
-            wave_lds_fence();
-            const u32x4 img = reinterpret_cast<const u32x4 *>(stage)[lane];
-            wave_lds_fence();
-            __builtin_nontemporal_store(img, reinterpret_cast<u32x4 *>(out + oi * 512) + lane);
+            for (int d = 0; d < 4; d++)                      // four coalesced 256-byte stores, in the layout as is
+                __builtin_nontemporal_store(cast_i16_bits(o[d].x) | (cast_i16_bits(o[d].y) << 16), dst + 64 * d);
             if (precast) {
 #pragma unroll
                 for (int d = 0; d < 4; d++) *reinterpret_cast<float2 *>(precast + oi * 512 + 2 * lane + 128 * d) = o[d];
             }
         }
         if (j == n_blocks - 1) {
-            reinterpret_cast<u32x4 *>(st_out->prev)[lane] = half[i + 2];        // SS:257
+#pragma unroll
+            for (int r = 0; r < 4; r++) reinterpret_cast<unsigned int *>(st_out->prev)[lane + 64 * r] = half[i + 2][r];   // SS:257
 #pragma unroll
             for (int d = 0; d < 4; d++) *reinterpret_cast<float2 *>(&st_out->tail[2 * lane + 128 * d]) = tail[d];
         }
