@@ -17,8 +17,12 @@
  *     every per-block function, e.g. SpectralSubtraction_final.cpp:202,208-209;
  *     here that state lives in the handle).
  *   - "_dev" entry points take DEVICE pointers and only enqueue work on the
- *     handle's HIP stream (no allocation, no synchronisation: graph-capturable);
- *     the plain entry points take HOST pointers, copy in, run, copy out and
+ *     handle's HIP stream: no allocation and no synchronisation once the
+ *     handle is warm, i.e. after one call of that entry point (constant tables
+ *     are built on first use) and after the matching *_reserve() where the
+ *     entry has a workspace (jdsp_denoise_reserve, jdsp_hmm_reserve).  A warm
+ *     "_dev" call can be captured into a hipGraph (bench.py does that).
+ *     The plain entry points take HOST pointers, copy in, run, copy out and
  *     synchronise.
  *   - spectra are interleaved (re, im) float pairs, full length n_fft per frame
  *     exactly like the reference's fftw_complex[FFT_PROCESSING_SIZE] buffers
