@@ -6,6 +6,7 @@
 set -eo pipefail
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out/final
+rm -rf "$O"
 mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
 echo "== pytest -m gpu"; timeout -k 10 900 python -m pytest "$R/tests" -m gpu -x -q 2>&1 | tail -3 | tee "$O/pytest.log"
