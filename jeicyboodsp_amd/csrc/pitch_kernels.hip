@@ -29,21 +29,24 @@ __global__ __launch_bounds__(64) void pitch_autocorr_kernel(const short *__restr
                                                             float *__restrict__ rmax, float *__restrict__ autocorr)
 {
     __shared__ __attribute__((aligned(16))) float2 lds[kWaveLdsComplex];
-    __shared__ __attribute__((aligned(16))) unsigned int stage[256];
     const int lane = threadIdx.x;
     const long per_xcd = (gridDim.x + 7) >> 3;
     const long b = (long)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
     if (b >= n_blocks) return;
-    u32x4 h0 = {0u, 0u, 0u, 0u};                                         // rgssKeepBuffer (:74,:79-81)
-    if (b > 0) h0 = reinterpret_cast<const u32x4 *>(pcm + (b - 1) * 512)[lane];
-    else if (prev_block) h0 = reinterpret_cast<const u32x4 *>(prev_block)[lane];
-    const u32x4 h1 = reinterpret_cast<const u32x4 *>(pcm + b * 512)[lane];
+    // raw[r]: the sample pair (2 lane + 128 r, +1) of the frame [keep buffer (:74,:79-81), block]: four
+    // coalesced dword loads per half, already in the transform's layout
+    const unsigned int *p0 = b > 0 ? reinterpret_cast<const unsigned int *>(pcm + (b - 1) * 512)
+                                   : reinterpret_cast<const unsigned int *>(prev_block);
+    const unsigned int *p1 = reinterpret_cast<const unsigned int *>(pcm + b * 512);
+    unsigned int raw[8];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        raw[r] = p0 ? p0[lane + 64 * r] : 0u;
+        raw[r + 4] = p1[lane + 64 * r];
+    }
     WaveTwiddles tw;
     load_wave_twiddles(tw, table, lane);
     const float2 wsp[2] = {table[kStftSplit + 2 * lane], table[kStftSplit + 2 * lane + 1]};
-    unsigned int raw[8];
-    relayout_half(stage, lane, h0, raw);
-    relayout_half(stage, lane, h1, raw + 4);
     float2 v[8];
 #pragma unroll
     for (int r = 0; r < 8; r++) {

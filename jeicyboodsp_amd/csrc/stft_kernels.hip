@@ -229,29 +229,32 @@ __global__ __launch_bounds__(64, JDSP_STFT_MINWAVES) void stft1024_hop512_half_k
     const float2 *__restrict__ table)
 {
     __shared__ __attribute__((aligned(16))) float2 lds[kWaveLdsComplex];
-    __shared__ __attribute__((aligned(16))) unsigned int stage[256];
     const int lane = threadIdx.x;
     const long per_xcd = (gridDim.x + 7) >> 3;
     const long f0 = ((long)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3)) * K;
     if (f0 >= n_frames) return;
-    const u32x4 *pcm128 = reinterpret_cast<const u32x4 *>(pcm) + lane;
-    u32x4 half[K + 1];
+    const unsigned int *pcm32 = reinterpret_cast<const unsigned int *>(pcm) + lane;   // sample pair per lane
+    unsigned int half[K + 1][4];
 #pragma unroll
-    for (int h = 0; h <= K; h++) half[h] = pcm128[(f0 + h <= n_frames ? f0 + h : n_frames) * 64];
+    for (int h = 0; h <= K; h++) {
+        const long hh = f0 + h <= n_frames ? f0 + h : n_frames;
+#pragma unroll
+        for (int q = 0; q < 4; q++) half[h][q] = pcm32[hh * 256 + 64 * q];
+    }
     FrameTables t;
     load_frame_tables(t, table, lane);
     static_assert(K % 2 == 0, "row parity is taken from the in-wave frame index");
     const float2 wsp2 = table[kStftSplit + 2 * lane + 2];        // W^(2 lane + 2); lane 63: W^128
     unsigned int raw[8];
-    relayout_half(stage, lane, half[0], raw + 4);
+#pragma unroll
+    for (int q = 0; q < 4; q++) raw[4 + q] = half[0][q];
 #pragma unroll
     for (int i = 0; i < K; i++) {
         const long f = f0 + i;
         if (f >= n_frames) break;
         float2 v[8];
 #pragma unroll
-        for (int r = 0; r < 4; r++) raw[r] = raw[r + 4];
-        relayout_half(stage, lane, half[i + 1], raw + 4);
+        for (int r = 0; r < 4; r++) { raw[r] = raw[r + 4]; raw[r + 4] = half[i + 1][r]; }
 #pragma unroll
         for (int r = 0; r < 8; r++) {
             const float2 s = unpack_i16x2(raw[r]);
