@@ -209,6 +209,9 @@ int jdsp_fastconv_set_position(jdsp_fastconv *h, long blocks_consumed);
 int jdsp_fastconv_block_len(const jdsp_fastconv *h);
 int jdsp_fastconv_hist_blocks(const jdsp_fastconv *h);
 long jdsp_fastconv_blocks_out(const jdsp_fastconv *h, long n_blocks);
+/* Sizes the workspace for calls of up to n_blocks blocks ahead of time (the 8192-point configuration with a
+ * block length that is a multiple of 512 runs as a partitioned convolution with a spectrum workspace). */
+int jdsp_fastconv_reserve(jdsp_fastconv *h, long n_blocks);
 int jdsp_fastconv_process_dev(jdsp_fastconv *h, const int16_t *pcm_dev, long n_blocks, int16_t *out_dev,
                               float *precast_dev, long *n_out_blocks);
 int jdsp_fastconv_process(jdsp_fastconv *h, const int16_t *pcm_host, long n_blocks, int16_t *out_host,

@@ -86,6 +86,7 @@ def _load():
         "jdsp_mfcc_frames": (i, [vp, vp, l, vp, l, vp]),
         "jdsp_fastconv_create": (i, [vp, vp, i, i, i, C.POINTER(vp)]),
         "jdsp_fastconv_destroy": (i, [vp]),
+        "jdsp_fastconv_reserve": (i, [vp, l]),
         "jdsp_fastconv_reset": (i, [vp]),
         "jdsp_fastconv_set_position": (i, [vp, l]),
         "jdsp_fastconv_block_len": (i, [vp]),

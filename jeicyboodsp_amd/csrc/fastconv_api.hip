@@ -49,6 +49,31 @@ int jdsp_fastconv_create(jdsp_ctx *ctx, const double *taps, int n_taps, int n_fi
     if (!rc && (e = hipStreamSynchronize(ctx->stream)) != hipSuccess) rc = fail(ctx, JDSP_EHIP, "jdsp_fastconv_create: sync", e);
     if (d_h) (void)hipFree(d_h);
     if (d_H) (void)hipFree(d_H);
+    // Uniformly partitioned form of the same convolution (fastconv_kernels.hip): spectra of the 512-tap
+    // partitions, each zero-padded to 1024, bins 0..512.  JDSP_FASTCONV_PARTITIONED=0 keeps the 8192-point kernel.
+    const char *env = getenv("JDSP_FASTCONV_PARTITIONED");
+    if (!rc && n_fft == 8192 && h->block % 512 == 0 && !(env && env[0] == '0')) {
+        const int P = (n_taps + 511) / 512;
+        const size_t rows = (size_t)n_filters * P;
+        std::vector<double> part(rows * 1024 * 2, 0.0);
+        for (int f = 0; f < n_filters; f++)
+            for (int i = 0; i < n_taps; i++)
+                part[2 * (((size_t)f * P + i / 512) * 1024 + i % 512)] = taps[(size_t)f * n_taps + i];
+        double *d_p = nullptr, *d_P = nullptr;
+        e = hipMalloc((void **)&d_p, rows * 1024 * 16);
+        if (e == hipSuccess) e = hipMalloc((void **)&d_P, rows * 1024 * 16);
+        if (e == hipSuccess) e = hipMalloc((void **)&h->Hp, rows * jdsp::kUpolsRowPitch * sizeof(float2));
+        if (e == hipSuccess) e = hipMemcpy(d_p, part.data(), rows * 1024 * 16, hipMemcpyHostToDevice);
+        if (e != hipSuccess) rc = fail(ctx, JDSP_EHIP, "jdsp_fastconv_create: partitions", e);
+        if (!rc) rc = jdsp::ensure_stft1024_table_rect(ctx);
+        if (!rc) rc = jdsp_fft_process_f64_dev(ctx, d_p, d_P, 1024, (long)rows, 1);
+        if (!rc && jdsp::launch_spectrum_rows_to_f32(ctx->stream, (const double2 *)d_P, h->Hp, (long)rows))
+            rc = fail(ctx, JDSP_EHIP, "spectrum_rows_to_f32 launch", hipGetLastError());
+        if (!rc && (e = hipStreamSynchronize(ctx->stream)) != hipSuccess) rc = fail(ctx, JDSP_EHIP, "jdsp_fastconv_create: sync", e);
+        if (d_p) (void)hipFree(d_p);
+        if (d_P) (void)hipFree(d_P);
+        if (!rc) h->n_part = P;
+    }
     if (!rc) rc = jdsp_fastconv_reset(h);
     if (rc) {
         jdsp_fastconv_destroy(h);
@@ -64,6 +89,9 @@ int jdsp_fastconv_destroy(jdsp_fastconv *h)
     (void)hipSetDevice(h->ctx->device);
     (void)hipStreamSynchronize(h->ctx->stream);
     if (h->H) (void)hipFree(h->H);
+    if (h->Hp) (void)hipFree(h->Hp);
+    if (h->staged) (void)hipFree(h->staged);
+    if (h->X) (void)hipFree(h->X);
     for (int i = 0; i < 2; i++)
         if (h->hist[i]) (void)hipFree(h->hist[i]);
     delete h;
@@ -86,6 +114,25 @@ int jdsp_fastconv_set_position(jdsp_fastconv *h, long blocks_consumed)
     int rc = jdsp_fastconv_reset(h);                 // history = silence; the caller feeds the halo blocks itself
     if (rc) return rc;
     h->calls = blocks_consumed;
+    return JDSP_OK;
+}
+
+int jdsp_fastconv_reserve(jdsp_fastconv *h, long n_blocks)
+{
+    if (!h || n_blocks < 0) return JDSP_EINVAL;
+    if (!h->n_part) return JDSP_OK;                  // only the partitioned path has a workspace
+    jdsp_ctx *ctx = h->ctx;
+    const long samples = n_blocks * h->block;
+    if (samples <= h->ws_samples) return JDSP_OK;
+    JDSP_HIP(ctx, hipSetDevice(ctx->device));
+    JDSP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (h->staged) (void)hipFree(h->staged);
+    if (h->X) (void)hipFree(h->X);
+    h->staged = nullptr; h->X = nullptr; h->ws_samples = 0;
+    const long total = 512L * h->n_part + samples;
+    JDSP_HIP(ctx, hipMalloc((void **)&h->staged, (size_t)total * sizeof(short)));
+    JDSP_HIP(ctx, hipMalloc((void **)&h->X, (size_t)(total / 512) * jdsp::kUpolsRowPitch * sizeof(float2)));
+    h->ws_samples = samples;
     return JDSP_OK;
 }
 
@@ -118,7 +165,14 @@ int jdsp_fastconv_process_dev(jdsp_fastconv *h, const int16_t *pcm_dev, long n_b
     s.valid_from = (long)h->n_hist * h->block;
     s.hist_len = h->n_taps - 1;
     const int first = (int)(n_blocks - n_out);
-    if (jdsp::launch_fastconv(ctx->stream, h->n_fft, s, n_out, first, h->block, h->n_taps, h->n_filters, h->H,
+    if (h->n_part) {
+        int rc = jdsp_fastconv_reserve(h, n_blocks);
+        if (rc) return rc;
+        if (jdsp::launch_fastconv_upols(ctx->stream, s, n_out, first, h->block, h->n_part, h->n_filters, h->Hp,
+                                        ctx->stft1024_table_rect, h->staged, h->X, out_dev, precast_dev, n_out * h->block,
+                                        h->hist[h->cur ^ 1]))
+            return fail(ctx, JDSP_EHIP, "fastconv (partitioned) launch", hipGetLastError());
+    } else if (jdsp::launch_fastconv(ctx->stream, h->n_fft, s, n_out, first, h->block, h->n_taps, h->n_filters, h->H,
                               ctx->stft1024_table, ctx->conv_tw4096, ctx->conv_tw8192, out_dev, precast_dev,
                               n_out * h->block, h->hist[h->cur ^ 1]))
         return fail(ctx, JDSP_EHIP, "fastconv launch", hipGetLastError());

@@ -283,6 +283,312 @@ int launch_fastconv(hipStream_t st, int n_fft, const ConvStream &s, long n_out_b
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
+// ---------------------------------------------------------------------------------------
+// n_fft = 8192 with a block length that is a multiple of 512 (the reference-native 8192 / 7169 / 1024):
+// the same linear convolution computed as a UNIFORMLY PARTITIONED overlap-save.  The 8192-point segment of
+// every 1024-sample block overlaps its predecessor by 7/8, so the reference shape transforms every sample
+// eight times; here the taps are cut into P = ceil(n_taps / 512) partitions of 512, every 512-sample
+// sub-block of the stream is transformed ONCE (1024-point frame [previous sub-block, sub-block], the
+// half-spectrum STFT kernel with a rectangular window), and output sub-block c is
+//     y_c = IDFT( sum_p X[c - p] H_p )   (second half of the 1024-point result),
+// the standard frequency-domain delay line.  Results equal the 8192-point formulation to FP32 rounding
+// (same sums, associated differently) and are checked against the same oracle.
+//   conv_stage_kernel   lays [history | this call's samples] out as one int16 run, with the reference's
+//                       silent head (conv_sample) already applied
+//   stft1024_hop512_half_kernel (stft_kernels.hip)   X rows, bins 0..512 at a pitch of 520
+//   fastconv_upols_kernel   one wave per output sub-block: P multiply-accumulates per bin from L2-resident
+//                       rows, Hermitian extension through LDS, pre-split, inverse wave FFT, cast
+__global__ void conv_stage_kernel(ConvStream s, long lead, long n_total, short *__restrict__ staged,
+                                  short *__restrict__ hist_out)
+{
+    const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 8;         // eight samples per thread
+    if (i >= n_total) return;
+    const long pos = i - lead;
+    const long hist0 = n_total - s.hist_len;                                  // the next call's history = the tail
+    if (pos >= 0 && pos + 8 <= s.n_samples && pos + s.global0 >= s.valid_from && i + 8 <= n_total &&
+        (((uintptr_t)(s.pcm + pos)) & 15u) == 0) {
+        const u32x4 v = *reinterpret_cast<const u32x4 *>(s.pcm + pos);
+        *reinterpret_cast<u32x4 *>(staged + i) = v;
+        if (i + 8 > hist0) {
+            const short *sv = reinterpret_cast<const short *>(&v);
+            for (int k = 0; k < 8; k++)
+                if (i + k >= hist0) hist_out[i + k - hist0] = sv[k];
+        }
+        return;
+    }
+    for (int k = 0; k < 8 && i + k < n_total; k++) {
+        const short v = (short)conv_sample(s, pos + k);
+        staged[i + k] = v;
+        // the history keeps the samples themselves, silent head or not (conv_hist_update_kernel)
+        if (i + k >= hist0) {
+            const long p = pos + k;
+            hist_out[i + k - hist0] = p >= 0 ? s.pcm[p] : (p + s.hist_len >= 0 ? s.hist[p + s.hist_len] : (short)0);
+        }
+    }
+}
+
+#ifndef JDSP_UPOLS_SIMPLE
+#define JDSP_UPOLS_SIMPLE 0       // 1: the one-wave-per-sub-block kernel (kept for comparison)
+#endif
+#ifndef JDSP_UPOLS_UNROLL
+#define JDSP_UPOLS_UNROLL 1       // partitions whose loads are in flight together
+#endif
+constexpr int kUpolsPitch = kUpolsRowPitch;   // 520 complex elements per spectrum row (513 used): 65 x 64 bytes
+
+template <int J>
+__device__ __forceinline__ void upols_presplit_j(const float2 *img, float2 *zout, int lane, const float2 *wsp)
+{
+    const int m = 128 * J + 2 * lane;
+    const float4 yy = *reinterpret_cast<const float4 *>(&img[m]);
+    float2 zr0, zr1;
+    load_mirror_pair(img, m, zr0, zr1);                              // Y[512 - m], Y[511 - m]
+    // Y[m + 512] = conj(Y[512 - m]): the output is real
+    zout[2 * J] = presplit_inv<J>(make_float2(yy.x, yy.y), make_float2(zr0.x, -zr0.y), wsp[0]);
+    zout[2 * J + 1] = presplit_inv<J>(make_float2(yy.z, yy.w), make_float2(zr1.x, -zr1.y), wsp[1]);
+}
+
+__global__ __launch_bounds__(64) void fastconv_upols_kernel(const float2 *__restrict__ X, const float2 *__restrict__ Hp,
+                                                            int n_part, int n_filters, long first_row, long n_sub,
+                                                            const float2 *__restrict__ table, short *__restrict__ out,
+                                                            float *__restrict__ precast, long plane)
+{
+    __shared__ __attribute__((aligned(16))) float2 lds[kWaveLdsComplex];
+    const int lane = threadIdx.x;
+    const long per_xcd = (gridDim.x + 7) >> 3;                        // neighbours share an XCD's L2: they read
+    const long t = (long)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);   // n_part - 1 of the same rows
+    if (t >= n_sub) return;
+    WaveTwiddles tw;
+    load_wave_twiddles(tw, table, lane);
+    const float2 wsp[2] = {table[kStftSplit + 2 * lane], table[kStftSplit + 2 * lane + 1]};
+    for (int f = 0; f < n_filters; f++) {
+        float2 acc[8], acc512 = make_float2(0.f, 0.f);
+#pragma unroll
+        for (int q = 0; q < 8; q++) acc[q] = make_float2(0.f, 0.f);
+        const float2 *xrow = X + (first_row + t) * kUpolsPitch;      // frame whose second half is this sub-block
+        const float2 *hrow = Hp + (size_t)f * n_part * kUpolsPitch;
+#pragma unroll JDSP_UPOLS_UNROLL
+        for (int p = 0; p < n_part; p++, xrow -= kUpolsPitch, hrow += kUpolsPitch) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int m = 128 * j + 2 * lane;
+                const float4 x = *reinterpret_cast<const float4 *>(xrow + m);
+                const float4 h = *reinterpret_cast<const float4 *>(hrow + m);
+                acc[2 * j] = cadd(acc[2 * j], cmul(make_float2(x.x, x.y), make_float2(h.x, h.y)));
+                acc[2 * j + 1] = cadd(acc[2 * j + 1], cmul(make_float2(x.z, x.w), make_float2(h.z, h.w)));
+            }
+            if (lane == 0) acc512 = cadd(acc512, cmul(xrow[512], hrow[512]));
+        }
+        // natural-order image of Y[0..512]
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            *reinterpret_cast<float4 *>(&lds[128 * j + 2 * lane]) = make_float4(acc[2 * j].x, acc[2 * j].y, acc[2 * j + 1].x, acc[2 * j + 1].y);
+        if (lane == 0) lds[512] = acc512;
+        wave_lds_fence();
+        float2 z[8], y[8];
+        upols_presplit_j<0>(lds, z, lane, wsp);
+        upols_presplit_j<1>(lds, z, lane, wsp);
+        upols_presplit_j<2>(lds, z, lane, wsp);
+        upols_presplit_j<3>(lds, z, lane, wsp);
+        wave_lds_fence();
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            *reinterpret_cast<float4 *>(&lds[128 * j + 2 * lane]) = make_float4(z[2 * j].x, z[2 * j].y, z[2 * j + 1].x, z[2 * j + 1].y);
+        wave_lds_fence();
+#pragma unroll
+        for (int r = 0; r < 8; r++) y[r] = lds[lane + 64 * r];
+        wave_lds_fence();
+        wave_fft512<true>(y, lds, lane, tw);
+        wave_lds_fence();
+        // samples 512..1023 of the frame are the valid ones: y[4..7] hold the pairs 2 lane + 128 d
+        unsigned int *o = reinterpret_cast<unsigned int *>(out + (size_t)f * plane + t * 512) + lane;
+        float *pc = precast ? precast + (size_t)f * plane + t * 512 : nullptr;
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+            const float2 v = make_float2(y[d + 4].x * (1.0f / 1024.0f), y[d + 4].y * (1.0f / 1024.0f));
+            __builtin_nontemporal_store(cast_i16_bits(v.x) | (cast_i16_bits(v.y) << 16), o + 64 * d);
+            if (pc) *reinterpret_cast<float2 *>(pc + 2 * lane + 128 * d) = v;
+        }
+    }
+}
+
+// The same sums with the traffic cut down: one workgroup = 4 waves, one wave = kUpolsK consecutive output
+// sub-blocks.  A row X[r] feeds sub-block t through H_(t-r), so a wave walking the rows it needs from the
+// newest down uses every row for up to kUpolsK outputs (P + kUpolsK - 1 rows from L2 instead of
+// kUpolsK * P), with the next row in flight while the current one is used, and the partition spectra sit in
+// LDS, loaded once per workgroup.  (One wave per sub-block reading P rows and P partition spectra from L2
+// ran at 22 TB/s of L2 traffic: 44 us for the native shape; profiles/r01_fastconv_partitioned.txt.)
+constexpr int kUpolsK = 4;
+constexpr int kUpolsDepth = 4;
+
+__global__ __launch_bounds__(256) void fastconv_upols4_kernel(const float2 *__restrict__ X, const float2 *__restrict__ Hp,
+                                                              int n_part, int n_filters, long first_row, long n_sub,
+                                                              long max_row, const float2 *__restrict__ table,
+                                                              short *__restrict__ out, float *__restrict__ precast,
+                                                              long plane)
+{
+    extern __shared__ __attribute__((aligned(16))) float2 smem[];
+    float2 *Hs = smem;                                                        // [n_part][520]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float2 *lds = smem + (size_t)n_part * kUpolsPitch + (size_t)wave * kWaveLdsComplex;   // this wave's scratch
+    const long per_xcd = (gridDim.x + 7) >> 3;
+    const long wg = (long)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    const long t0 = (wg * 4 + wave) * kUpolsK;
+    const bool live = t0 < n_sub;
+    for (int f = 0; f < n_filters; f++) {
+        {
+            const float4 *src = reinterpret_cast<const float4 *>(Hp + (size_t)f * n_part * kUpolsPitch);
+            float4 *dst = reinterpret_cast<float4 *>(Hs);
+            for (int i = threadIdx.x; i < n_part * (kUpolsPitch / 2); i += 256) dst[i] = src[i];
+        }
+        __syncthreads();
+        if (live) {
+            float2 acc[kUpolsK][8], acc512[kUpolsK];
+#pragma unroll
+            for (int k = 0; k < kUpolsK; k++) {
+                acc512[k] = make_float2(0.f, 0.f);
+#pragma unroll
+                for (int q = 0; q < 8; q++) acc[k][q] = make_float2(0.f, 0.f);
+            }
+            const long r_top = first_row + t0 + (kUpolsK - 1);
+            auto row_of = [&](int q) {
+                long r = r_top - q;
+                return X + (r > max_row ? max_row : r) * kUpolsPitch;        // rows past the end feed no written output
+            };
+            // kUpolsDepth rows in flight: an iteration is ~100 VALU instructions, an L2 round trip several times that
+            float4 xb[kUpolsDepth][4];
+            float2 xb512[kUpolsDepth];
+#pragma unroll
+            for (int u = 0; u < kUpolsDepth; u++) {
+                const float2 *xr = row_of(u);
+#pragma unroll
+                for (int j = 0; j < 4; j++) xb[u][j] = *reinterpret_cast<const float4 *>(xr + 128 * j + 2 * lane);
+                xb512[u] = xr[512];
+            }
+            const int n_iter = n_part + kUpolsK - 1;
+            for (int q0 = 0; q0 < n_iter; q0 += kUpolsDepth) {
+#pragma unroll
+                for (int u = 0; u < kUpolsDepth; u++) {
+                    const int q = q0 + u;                                    // q >= n_iter: every p below is out of range
+#pragma unroll
+                    for (int k = 0; k < kUpolsK; k++) {
+                        const int p = q - (kUpolsK - 1) + k;                 // wave-uniform
+                        if (p < 0 || p >= n_part) continue;
+                        const float2 *hr = Hs + p * kUpolsPitch;
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            const float4 h = *reinterpret_cast<const float4 *>(hr + 128 * j + 2 * lane);
+                            const float4 x = xb[u][j];
+                            acc[k][2 * j] = cadd(acc[k][2 * j], cmul(make_float2(x.x, x.y), make_float2(h.x, h.y)));
+                            acc[k][2 * j + 1] = cadd(acc[k][2 * j + 1], cmul(make_float2(x.z, x.w), make_float2(h.z, h.w)));
+                        }
+                        acc512[k] = cadd(acc512[k], cmul(xb512[u], hr[512]));
+                    }
+                    if (q + kUpolsDepth < n_iter) {                          // refill this slot
+                        const float2 *xr = row_of(q + kUpolsDepth);
+#pragma unroll
+                        for (int j = 0; j < 4; j++) xb[u][j] = *reinterpret_cast<const float4 *>(xr + 128 * j + 2 * lane);
+                        xb512[u] = xr[512];
+                    }
+                }
+            }
+            WaveTwiddles tw;
+            load_wave_twiddles(tw, table, lane);
+            const float2 wsp[2] = {table[kStftSplit + 2 * lane], table[kStftSplit + 2 * lane + 1]};
+#pragma unroll
+            for (int k = 0; k < kUpolsK; k++) {
+                const long t = t0 + k;
+                if (t >= n_sub) break;
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    *reinterpret_cast<float4 *>(&lds[128 * j + 2 * lane]) =
+                        make_float4(acc[k][2 * j].x, acc[k][2 * j].y, acc[k][2 * j + 1].x, acc[k][2 * j + 1].y);
+                if (lane == 0) lds[512] = acc512[k];
+                wave_lds_fence();
+                float2 z[8], y[8];
+                upols_presplit_j<0>(lds, z, lane, wsp);
+                upols_presplit_j<1>(lds, z, lane, wsp);
+                upols_presplit_j<2>(lds, z, lane, wsp);
+                upols_presplit_j<3>(lds, z, lane, wsp);
+                wave_lds_fence();
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    *reinterpret_cast<float4 *>(&lds[128 * j + 2 * lane]) = make_float4(z[2 * j].x, z[2 * j].y, z[2 * j + 1].x, z[2 * j + 1].y);
+                wave_lds_fence();
+#pragma unroll
+                for (int r = 0; r < 8; r++) y[r] = lds[lane + 64 * r];
+                wave_lds_fence();
+                wave_fft512<true>(y, lds, lane, tw);
+                wave_lds_fence();
+                unsigned int *o = reinterpret_cast<unsigned int *>(out + (size_t)f * plane + t * 512) + lane;
+                float *pc = precast ? precast + (size_t)f * plane + t * 512 : nullptr;
+#pragma unroll
+                for (int d = 0; d < 4; d++) {
+                    const float2 v = make_float2(y[d + 4].x * (1.0f / 1024.0f), y[d + 4].y * (1.0f / 1024.0f));
+                    __builtin_nontemporal_store(cast_i16_bits(v.x) | (cast_i16_bits(v.y) << 16), o + 64 * d);
+                    if (pc) *reinterpret_cast<float2 *>(pc + 2 * lane + 128 * d) = v;
+                }
+            }
+        }
+        __syncthreads();                                                     // Hs is rewritten for the next filter
+    }
+}
+
+// bins 0..512 of `rows` 1024-point FP64 spectra -> float rows at the partitioned convolver's pitch
+__global__ void spectrum_rows_to_f32_kernel(const double2 *__restrict__ in, float2 *__restrict__ out, long rows)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * kUpolsPitch) return;
+    const long r = i / kUpolsPitch;
+    const int b = (int)(i % kUpolsPitch);
+    out[i] = b <= 512 ? make_float2((float)in[r * 1024 + b].x, (float)in[r * 1024 + b].y) : make_float2(0.f, 0.f);
+}
+
+int launch_spectrum_rows_to_f32(hipStream_t s, const double2 *in, float2 *out, long rows)
+{
+    const long n = rows * kUpolsPitch;
+    hipLaunchKernelGGL(spectrum_rows_to_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, out, rows);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+int launch_fastconv_upols(hipStream_t st, const ConvStream &s, long n_out_blocks, int first_block, int block, int n_part,
+                          int n_filters, const float2 *Hp, const float2 *rect_table, short *staged, float2 *X,
+                          short *out, float *precast, long plane, short *hist_out)
+{
+    const long lead = 512L * n_part;
+    const long n_total = lead + s.n_samples;
+    const long n_frames = n_total / 512 - 1;                          // frame f = staged[512 f, 512 f + 1024)
+    if (n_out_blocks > 0) {
+        hipLaunchKernelGGL(conv_stage_kernel, dim3((unsigned)((n_total / 8 + 256) / 256)), dim3(256), 0, st, s, lead, n_total,
+                           staged, s.hist_len > 0 ? hist_out : nullptr);
+        if (launch_stft1024_half(st, staged, n_frames, X, kUpolsPitch, rect_table)) return -1;
+        const long n_sub = n_out_blocks * (block / 512);
+        // output sub-block t = call-local samples [first_block * block + 512 t, +512) = staged sub-block
+        // n_part + first_block * block / 512 + t = the second half of frame (that index - 1)
+        const long first_row = n_part + (long)first_block * (block / 512) - 1;
+#if JDSP_UPOLS_SIMPLE
+        const long grid = (n_sub + 7) / 8 * 8;
+        hipLaunchKernelGGL(fastconv_upols_kernel, dim3((unsigned)grid), dim3(64), 0, st, X, Hp, n_part, n_filters, first_row,
+                           n_sub, rect_table, out, precast, plane);
+#else
+        const long per_wg = 4 * kUpolsK;
+        const long grid = ((n_sub + per_wg - 1) / per_wg + 7) / 8 * 8;
+        const size_t lds = ((size_t)n_part * kUpolsPitch + 4 * (size_t)kWaveLdsComplex) * sizeof(float2);
+        static bool attr_set = false;
+        if (!attr_set) {
+            if (hipFuncSetAttribute((const void *)fastconv_upols4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)((16 * (size_t)kUpolsPitch + 4 * (size_t)kWaveLdsComplex) * sizeof(float2))) != hipSuccess)
+                return -1;
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(fastconv_upols4_kernel, dim3((unsigned)grid), dim3(256), lds, st, X, Hp, n_part, n_filters,
+                           first_row, n_sub, n_frames - 1, rect_table, out, precast, plane);
+#endif
+    }
+    if (s.hist_len > 0 && n_out_blocks <= 0)                           // otherwise the staging kernel wrote it
+        hipLaunchKernelGGL(conv_hist_update_kernel, dim3((s.hist_len + 255) / 256), dim3(256), 0, st, s, hist_out);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 void fill_conv_twiddles(float2 *tw4096, float2 *tw8192)
 {
     const double two_pi = 6.283185307179586476925286766559;

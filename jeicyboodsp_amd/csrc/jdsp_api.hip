@@ -28,6 +28,17 @@ int ensure_stft1024_table(jdsp_ctx *ctx)
     return 0;
 }
 
+int ensure_stft1024_table_rect(jdsp_ctx *ctx)
+{
+    if (ctx->stft1024_table_rect) return 0;
+    const int n = stft1024_table_count();
+    std::vector<float2> host((size_t)n);
+    fill_stft1024_table(host.data(), 2);
+    JDSP_HIP(ctx, hipMalloc((void **)&ctx->stft1024_table_rect, sizeof(float2) * (size_t)n));
+    JDSP_HIP(ctx, hipMemcpy(ctx->stft1024_table_rect, host.data(), sizeof(float2) * (size_t)n, hipMemcpyHostToDevice));
+    return 0;
+}
+
 int ensure_vad_window(jdsp_ctx *ctx)
 {
     if (ctx->vad_w_hi) return 0;
@@ -92,6 +103,7 @@ int jdsp_destroy(jdsp_ctx *ctx)
     if (ctx->win512) (void)hipFree(ctx->win512);
     if (ctx->win512_hann) (void)hipFree(ctx->win512_hann);
     if (ctx->stft1024_table_hann) (void)hipFree(ctx->stft1024_table_hann);
+    if (ctx->stft1024_table_rect) (void)hipFree(ctx->stft1024_table_rect);
     for (auto &p : ctx->pipe_buf)
         if (p) (void)hipFree(p);
     for (auto &ev : ctx->pipe_ev)

@@ -22,6 +22,7 @@ struct jdsp_ctx {
     int opt_stft_fpw = 0;              // 0 = auto
     int opt_stft_window = 0;           // 0 Hamming (the reference), 1 Hann -- jdsp_stft_* only
     float2 *stft1024_table_hann = nullptr, *win512_hann = nullptr;
+    float2 *stft1024_table_rect = nullptr;   // rectangular window: the partitioned convolver's forward frames
     // device tables, created on first use
     float2 *stft1024_table = nullptr;
     float2 *win512 = nullptr;          // halved Hamming-512 pairs
@@ -147,6 +148,12 @@ int launch_fastconv(hipStream_t st, int n_fft, const ConvStream &s, long n_out_b
                     int n_taps, int n_filters, const float2 *H, const float2 *table, const float2 *tw4096,
                     const float2 *tw8192, short *out, float *precast, long plane, short *hist_out);
 void fill_conv_twiddles(float2 *tw4096, float2 *tw8192);
+constexpr int kUpolsRowPitch = 520;      // = kUpolsPitch in fastconv_kernels.hip
+int launch_spectrum_rows_to_f32(hipStream_t s, const double2 *in, float2 *out, long rows);
+int launch_fastconv_upols(hipStream_t st, const ConvStream &s, long n_out_blocks, int first_block, int block, int n_part,
+                          int n_filters, const float2 *Hp, const float2 *rect_table, short *staged, float2 *X,
+                          short *out, float *precast, long plane, short *hist_out);
+int ensure_stft1024_table_rect(jdsp_ctx *ctx);
 // mvdr_kernels.hip
 int launch_mvdr(hipStream_t s, const short *left, const short *right, long n_blocks, long calls_before,
                 const MvdrState *st_in, MvdrState *st_out, const int *events, const DenoisePlan *plan,
@@ -238,6 +245,12 @@ struct jdsp_fastconv {
     jdsp_ctx *ctx = nullptr;
     int n_fft = 0, n_taps = 0, n_filters = 0, block = 0, n_hist = 0;
     float2 *H = nullptr;                  // [n_filters][n_fft]
+    // uniformly partitioned path (n_fft 8192, block % 512 == 0): see fastconv_kernels.hip
+    int n_part = 0;                       // 0: not used
+    float2 *Hp = nullptr;                 // [n_filters][n_part][520]: bins 0..512 of every 512-tap partition
+    short *staged = nullptr;              // [512 n_part + samples of a call]
+    float2 *X = nullptr;                  // [frames][520]
+    long ws_samples = 0;                  // samples per call the workspace is sized for
     short *hist[2] = {nullptr, nullptr};  // last n_taps-1 samples of the stream, ping-pong
     int cur = 0;
     long calls = 0;                       // blocks consumed so far (siNumOfCount)

@@ -425,8 +425,10 @@ int stft1024_table_count() { return kStftTableCount; }
 // Host-side table contents (double precision, rounded once to float).
 void fill_stft1024_table(float2 *t, int window_kind)
 {
-    // window_kind 0: the reference's Hamming 0.54 - 0.46 cos; 1: Hann 0.5 - 0.5 cos (same argument)
-    const double wa = window_kind == 1 ? 0.5 : 0.54, wb = window_kind == 1 ? 0.5 : 0.46;
+    // window_kind 0: the reference's Hamming 0.54 - 0.46 cos; 1: Hann 0.5 - 0.5 cos (same argument);
+    // 2: rectangular (the partitioned convolver's frames are not windowed)
+    const double wa = window_kind == 2 ? 1.0 : (window_kind == 1 ? 0.5 : 0.54);
+    const double wb = window_kind == 2 ? 0.0 : (window_kind == 1 ? 0.5 : 0.46);
     const double two_pi = 6.283185307179586476925286766559;
     for (int k = 1; k < 8; k++)
         for (int l = 0; l < 64; l++) {

@@ -21,6 +21,15 @@ def eng():
     e.close()
 
 
+@pytest.fixture(params=["partitioned", "8192-point"], autouse=True)
+def conv_impl(request, monkeypatch):
+    """The 8192-point configuration has two kernels for the same convolution (fastconv_kernels.hip): the
+    uniformly partitioned one (default when the block length is a multiple of 512) and the 8192-point
+    overlap-save shaped like the reference; the switch is read when a handle is created."""
+    monkeypatch.setenv("JDSP_FASTCONV_PARTITIONED", "1" if request.param == "partitioned" else "0")
+    return request.param
+
+
 def _pcm(seed, n, sigma=2000.0):
     rng = np.random.default_rng(seed)
     return np.clip(np.rint(rng.normal(0.0, sigma, n)), -32768, 32767).astype(np.int16)
@@ -152,3 +161,25 @@ def test_sharded_convolution_equals_single(eng, oracle, golden_dir, world):
     res = torch.cat(parts).cpu().numpy()
     assert res.shape == o_out.shape
     assert np.abs(res.astype(np.int32) - o_out.astype(np.int32)).max() <= 1
+
+
+@pytest.mark.parametrize("n_taps,block", [(6657, 1536), (7681, 512), (513, 7680), (1, 8192), (7000, 1193)])
+def test_8192_other_tap_counts_and_a_filter_pair(eng, oracle, n_taps, block):
+    """Block lengths that are multiples of 512 run partitioned (1 to 16 partitions, a last partition of one
+    tap, several sub-blocks per block); 7000 taps (block 1193) always takes the 8192-point kernel."""
+    rng = np.random.default_rng(n_taps)
+    taps = rng.normal(size=(2, n_taps)) * np.exp(-np.arange(n_taps) / 900.0) * 0.05
+    hist = -(-(n_taps - 1) // block)
+    n_blocks = hist + 5
+    pcm = _pcm(n_taps + 1, n_blocks * block)
+    fc = eng.fastconv(taps, 8192)
+    assert fc.block == block and fc.hist_blocks == hist
+    outs, pres = [], []
+    for lo, hi in [(0, 2), (2, n_blocks)]:                           # two calls: state carried across them
+        o, p = fc.process(pcm[lo * block:hi * block], want_precast=True)
+        outs.append(o); pres.append(p)
+    out, pre = np.concatenate(outs, axis=1), np.concatenate(pres, axis=1)
+    for f in range(2):
+        o_out, o_pre = oracle.fastconv_stream(pcm, taps[f], 8192)
+        check(out[f], pre[f], o_out, o_pre, floor=np.abs(pcm).max() * np.abs(taps[f]).sum())
+    fc.close()
