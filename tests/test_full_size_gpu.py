@@ -150,3 +150,23 @@ def test_gmm_full_batch_sample_vs_oracle_and_order_invariance(eng, oracle):
     s_rev, b_rev = g.score(torch.from_numpy(x_rev).cuda(), torch.from_numpy(first_rev).cuda())
     assert np.array_equal(s_rev.cpu().numpy()[::-1], scores) and np.array_equal(b_rev.cpu().numpy()[::-1], best)
     g.close()
+
+
+def test_partitioned_convolver_equals_the_8192_point_kernel_at_4096_blocks(eng, monkeypatch):
+    """Both formulations of the reference-native convolution on the bench's 4,096-block call, fed as one
+    stream in two calls: same samples to FP32 rounding (pre-cast within 1e-5 of the peak, int16 within 1 LSB)."""
+    rng = np.random.default_rng(6)
+    taps = rng.normal(size=7169) * np.exp(-np.arange(7169) / 1500.0) * 0.02
+    pcm = np.clip(np.rint(rng.normal(0, 2000, 4096 * 1024)), -32768, 32767).astype(np.int16)
+    res = {}
+    for name, flag in (("partitioned", "1"), ("direct", "0")):
+        monkeypatch.setenv("JDSP_FASTCONV_PARTITIONED", flag)
+        fc = eng.fastconv(taps, 8192)
+        o1, p1 = fc.process(pcm[:1000 * 1024], want_precast=True)
+        o2, p2 = fc.process(pcm[1000 * 1024:], want_precast=True)
+        res[name] = (np.concatenate([o1[0], o2[0]]), np.concatenate([p1[0], p2[0]]))
+        fc.close()
+    (oa, pa), (ob, pb) = res["partitioned"], res["direct"]
+    assert oa.shape == ob.shape == ((4096 - 7) * 1024,)
+    assert np.abs(pa - pb).max() < 1e-5 * np.abs(pb).max()
+    assert np.abs(oa.astype(np.int32) - ob.astype(np.int32)).max() <= 1
