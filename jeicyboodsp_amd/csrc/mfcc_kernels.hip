@@ -74,8 +74,9 @@ __global__ __launch_bounds__(64) void mfcc_kernel(const short *__restrict__ pcm,
         if (j == 1) { split_fwd<1>(make_float2(zz.x, zz.y), zr0, wsp0, lo0, hi0); split_fwd<1>(make_float2(zz.z, zz.w), zr1, wsp1, lo1, hi1); }
         if (j == 2) { split_fwd<2>(make_float2(zz.x, zz.y), zr0, wsp0, lo0, hi0); split_fwd<2>(make_float2(zz.z, zz.w), zr1, wsp1, lo1, hi1); }
         if (j == 3) { split_fwd<3>(make_float2(zz.x, zz.y), zr0, wsp0, lo0, hi0); split_fwd<3>(make_float2(zz.z, zz.w), zr1, wsp1, lo1, hi1); }
-        const float a0 = sqrtf(lo0.x * lo0.x + lo0.y * lo0.y);
-        const float a1 = sqrtf(lo1.x * lo1.x + lo1.y * lo1.y);
+        // hardware square root (1 ulp; sqrtf() expands to ~10 instructions of scaling and fix-up per value)
+        const float a0 = __builtin_amdgcn_sqrtf(lo0.x * lo0.x + lo0.y * lo0.y);
+        const float a1 = __builtin_amdgcn_sqrtf(lo1.x * lo1.x + lo1.y * lo1.y);
         if (p.bin_stride == 1) *reinterpret_cast<float2 *>(&mag[m]) = make_float2(a0, a1);
         else mag[m >> 1] = a0;                               // 512-point bins = even 1024-point bins
     }
