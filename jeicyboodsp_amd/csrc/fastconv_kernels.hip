@@ -292,7 +292,7 @@ int launch_fastconv(hipStream_t st, int n_fft, const ConvStream &s, long n_out_b
 // half-spectrum STFT kernel with a rectangular window), and output sub-block c is
 //     y_c = IDFT( sum_p X[c - p] H_p )   (second half of the 1024-point result),
 // the standard frequency-domain delay line.  Results equal the 8192-point formulation to FP32 rounding
-// (same sums, associated differently) and are checked against the same oracle.
+// (same sums, associated differently) and are held to the same parity tests.
 //   conv_stage_kernel   lays [history | this call's samples] out as one int16 run, with the reference's
 //                       silent head (conv_sample) already applied
 //   stft1024_hop512_half_kernel (stft_kernels.hip)   X rows, bins 0..512 at a pitch of 520
