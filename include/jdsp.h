@@ -331,6 +331,11 @@ typedef struct jdsp_gmm jdsp_gmm;
  * uploaded: eigenVector, mean[k][0..3], covariance[k][i][i] for i < 4. */
 int jdsp_gmm_create(jdsp_ctx *ctx, const jdsp_gmm_param *classes, int n_classes, jdsp_gmm **out);
 int jdsp_gmm_destroy(jdsp_gmm *h);
+/* "evaluation": 0 (default) evaluates probability() in the reference's operation order (un-fused products
+ * and sums, IEEE division, four exp per mixture: GMMTest:228-233); 1 fuses it (FMA projection, -0.5/var
+ * precomputed, one exp per mixture) -- about a third of the instructions, equal to a few 1e-16 relative
+ * except where a mixture density is itself denormal. */
+int jdsp_gmm_set_option(jdsp_gmm *h, const char *name, long value);
 /* Recognition() (GMMTest:151-162) of every utterance against every class and main()'s arg-max
  * (GMMTest:113-127: `dMax < score`, first maximum wins).  scores: [n_utts][n_classes] doubles,
  * best (may be NULL): [n_utts] 0-based class indices.  feats: n_frames vectors, 16-byte aligned; offsets

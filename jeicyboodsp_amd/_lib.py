@@ -71,6 +71,7 @@ def _load():
         "jdsp_denoise_vad_trace": (i, [vp, l, vp, vp, vp]),
         "jdsp_gmm_create": (i, [vp, vp, i, C.POINTER(vp)]),
         "jdsp_gmm_destroy": (i, [vp]),
+        "jdsp_gmm_set_option": (i, [vp, C.c_char_p, l]),
         "jdsp_gmm_score_dev": (i, [vp, vp, l, vp, l, vp, vp]),
         "jdsp_gmm_score": (i, [vp, vp, vp, l, vp, vp]),
         "jdsp_hmm_create": (i, [vp, vp, i, C.POINTER(vp)]),

@@ -19,7 +19,11 @@ void pack_gmm(const jdsp_gmm_param &p, double *r)
             r[jdsp::kGmmMean + 4 * k + i] = p.mean[k][i];
             r[jdsp::kGmmVar + 4 * k + i] = c;
             r[jdsp::kGmmCoef + 4 * k + i] = (1.0 / sqrt(2.0 * PI)) * (1.0 / sqrt(c));
+            r[jdsp::kGmmNhiv + 4 * k + i] = -0.5 / c;
         }
+        double cp = 1.0;
+        for (int i = 0; i < 4; i++) cp *= r[jdsp::kGmmCoef + 4 * k + i];
+        r[jdsp::kGmmCprod + k] = cp;
         for (int i = 0; i < 12; i++)
             for (int j = 0; j < 4; j++) r[jdsp::kGmmEig + 48 * k + 4 * i + j] = p.eigenVector[k][i][j];
     }
@@ -81,6 +85,17 @@ int jdsp_gmm_destroy(jdsp_gmm *h)
     return JDSP_OK;
 }
 
+int jdsp_gmm_set_option(jdsp_gmm *h, const char *name, long value)
+{
+    if (!h || !name) return JDSP_EINVAL;
+    if (!strcmp(name, "evaluation")) {
+        if (value != 0 && value != 1) return fail(h->ctx, JDSP_EINVAL, "jdsp_gmm_set_option: evaluation is 0 or 1");
+        h->fused = (int)value;
+        return JDSP_OK;
+    }
+    return fail(h->ctx, JDSP_EINVAL, "jdsp_gmm_set_option: unknown option");
+}
+
 int jdsp_gmm_score_dev(jdsp_gmm *h, const double *feats_dev, long n_frames, const int64_t *utt_first_dev, long n_utts,
                        double *scores_dev, int *best_dev)
 {
@@ -92,7 +107,7 @@ int jdsp_gmm_score_dev(jdsp_gmm *h, const double *feats_dev, long n_frames, cons
     if (n_utts == 0) return JDSP_OK;
     JDSP_HIP(ctx, hipSetDevice(ctx->device));
     if (jdsp::launch_gmm_score(ctx->stream, feats_dev, n_frames, (const long long *)utt_first_dev, n_utts, h->records, h->n_classes,
-                               scores_dev, best_dev))
+                               h->fused, scores_dev, best_dev))
         return fail(ctx, JDSP_EHIP, "gmm score launch", hipGetLastError());
     return JDSP_OK;
 }

@@ -178,11 +178,13 @@ int launch_pitch(hipStream_t s, const short *pcm, long n_blocks, const short *pr
                  float *rmax, float *autocorr);
 // mfcc_kernels.hip
 // ---- GMM / HMM (gmm_kernels.hip) ----
-// packed per-GMM record (doubles): alpa[4], mean[4][4], var[4][4], coef[4][4], eig[4][12][4]
-constexpr int kGmmAlpa = 0, kGmmMean = 4, kGmmVar = 20, kGmmCoef = 36, kGmmEig = 52, kGmmRecord = 244;
+// packed per-GMM record (doubles): alpa[4], mean[4][4], var[4][4], coef[4][4], eig[4][12][4], and for the
+// fused evaluation nhiv[4][4] = -0.5 / var and cprod[4] = the product of a mixture's four coef
+constexpr int kGmmAlpa = 0, kGmmMean = 4, kGmmVar = 20, kGmmCoef = 36, kGmmEig = 52, kGmmNhiv = 244, kGmmCprod = 260,
+              kGmmRecord = 264;
 constexpr int kGmmMaxClasses = 256;
 int launch_gmm_score(hipStream_t stream, const double *feats, long n_frames, const long long *utt_first, long n_utts,
-                     const double *gmm, int n_classes, double *scores, int *best);
+                     const double *gmm, int n_classes, int fused, double *scores, int *best);
 int launch_hmm_viterbi(hipStream_t stream, const double *feats, long n_frames, const long long *utt_first, long n_utts,
                        const double *gmm, const double *log_trans, int n_models, double log_init, double *b,
                        double *scores, int *best, int *path, double *trellis);
@@ -229,6 +231,7 @@ struct jdsp_mfcc {
 struct jdsp_gmm {
     jdsp_ctx *ctx = nullptr;
     int n_classes = 0;
+    int fused = 0;                        // "evaluation" option: 0 the reference's operation order, 1 fused
     double *records = nullptr;            // [n_classes][kGmmRecord]
 };
 

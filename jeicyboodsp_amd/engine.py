@@ -407,6 +407,9 @@ class Gmm(_Child):
         self._h = h
         engine._children.append(self)
 
+    def set_option(self, name, value):
+        self.eng._ck(L.jdsp_gmm_set_option(self._h, name.encode(), int(value)))
+
     def score(self, feats, utt_first):
         """feats [n_vectors, 12] float64, utt_first [n_utts + 1] int64 -> (scores [n_utts, n_classes], best [n_utts]).
         torch CUDA tensors stay on the device; numpy arrays go through the host entry."""

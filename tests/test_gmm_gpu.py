@@ -50,6 +50,36 @@ def test_gmm_scores_and_argmax_over_a_ragged_batch(eng, oracle):
     g.close()
 
 
+def test_gmm_fused_evaluation_option(eng, oracle):
+    """jdsp_gmm_set_option("evaluation", 1): same densities with FMA projections and one exp per mixture;
+    held to 1e-11 relative (a few 1e-16 per operation times the size of the exponent) and the same classes."""
+    import jeicyboodsp_amd
+    classes = gc.gmm_records(31, 25)
+    first = gc.offsets(LENGTHS)
+    x = gc.vectors(32, int(first[-1]))
+    g = eng.gmm(classes)
+    ref_scores, ref_best = g.score(x, first)
+    g.set_option("evaluation", 1)
+    scores, best = g.score(x, first)
+    for u in range(len(LENGTHS)):
+        want, arg = oracle.gmm_classify(x[first[u]:first[u + 1]], classes)
+        assert np.all(np.abs(scores[u] - want) <= 1e-11 * np.abs(want))
+        assert best[u] == arg
+    assert not np.array_equal(scores, ref_scores)                    # it really is a different evaluation
+    assert np.array_equal(best, ref_best)
+    far = np.full((4, 12), 1e6)                                       # total underflow: -inf either way
+    s, b = g.score(far, np.array([0, 4], np.int64))
+    assert np.all(np.isneginf(s)) and b[0] == 0
+    g.set_option("evaluation", 0)
+    again, _ = g.score(x, first)
+    assert np.array_equal(again, ref_scores)
+    with pytest.raises(jeicyboodsp_amd.JdspError):
+        g.set_option("evaluation", 2)
+    with pytest.raises(jeicyboodsp_amd.JdspError):
+        g.set_option("no_such_option", 1)
+    g.close()
+
+
 @pytest.mark.parametrize("n_classes", [1, 3, 4, 5, 64, 256])
 def test_gmm_class_counts(eng, oracle, n_classes):
     classes = gc.gmm_records(20 + n_classes, n_classes)

@@ -155,6 +155,10 @@ def main():
         report("gmm_score_25_classes_10k_utterances", ms, nvec, "vectors", 96, 25 * 550,
                "FP64; %d vectors in 10,000 utterances against 25 four-mixture GMMs; flops are FP64" % nvec,
                cpu=cpu_rate(lambda: orc.gmm_classify(feats_h[:2000], classes), 2000))
+        g.set_option("evaluation", 1)
+        ms = timed(lambda: g.score(feats, first_d), max(a.iters // 8, 3))
+        report("gmm_score_25_classes_10k_utterances_fused_evaluation", ms, nvec, "vectors", 96, 25 * 250,
+               "opt-in: FMA projections, -0.5/var precomputed, one exp per mixture (jdsp_gmm_set_option evaluation=1)")
         g.close()
         models = gc.hmm_records(2, 1)
         h = eng.hmm(models)
