@@ -138,7 +138,8 @@ __global__ __launch_bounds__(64) void mvdrn_update_kernel(const float2 *__restri
             den.y += cdv.x * xd.y - cdv.y * xd.x;
         }
         const cd w = cd_mul(b, cd_inv(den));
-        if (c == 0 && r < n_mics) weights[((size_t)v * kMvnBins + k) * 8 + r] = make_float2((float)w.x, (float)w.y);
+        // [version][microphone][bin]: the apply kernel reads one microphone's weights for consecutive bins
+        if (c == 0 && r < n_mics) weights[((size_t)v * 8 + r) * kMvnBins + k] = make_float2((float)w.x, (float)w.y);
     }
     cov_out[(size_t)k * 64 + lane] = make_double2(R.x, R.y);
 }
@@ -178,10 +179,11 @@ __global__ __launch_bounds__(64) void mvdrn_apply_kernel(const short *__restrict
         for (int q = 0; q < 8; q++) {
             const int bin = 128 * (q >> 1) + 2 * lane + (q & 1);            // 0..511; its partner is bin + 512
             // Y[k] = sum_m conj(w_k[m]) X_m[k];  for k > 512, w_k = conj(w_{1024-k})
-            const float2 wl = W[(size_t)bin * 8 + m];
+            const float2 *Wm = W + (size_t)m * kMvnBins;
+            const float2 wl = Wm[bin];
             ylo[q].x += wl.x * lo[q].x + wl.y * lo[q].y;
             ylo[q].y += wl.x * lo[q].y - wl.y * lo[q].x;
-            const float2 wh = W[(size_t)(512 - bin) * 8 + m];               // bin + 512 mirrors to 512 - bin
+            const float2 wh = Wm[512 - bin];                                // bin + 512 mirrors to 512 - bin
             if (bin == 0) {                                                 // k = 512 itself: not mirrored
                 yhi[q].x += wh.x * hi[q].x + wh.y * hi[q].y;
                 yhi[q].y += wh.x * hi[q].y - wh.y * hi[q].x;
