@@ -258,3 +258,37 @@ def test_compat_awgn_analysis_autocorrelation(tmp_path, oracle):
     assert np.abs(got - want).max() <= 1e-5 * np.abs(want[:, 0]).max()
     # white noise: R(0) ~ energy of the two blocks in the frame, other lags far below it (the program's point)
     assert np.all(np.abs(got[1:, 1:]).max(axis=1) < 0.2 * got[1:, 0])
+
+
+def test_plain_c_example_mfcc_to_gmm_on_the_device(tmp_path, oracle):
+    """examples/mfcc_gmm_pipeline.c: the C ABI from C99 -- PCM -> jdsp_mfcc_frames_dev -> jdsp_gmm_score_dev with
+    the vectors staying in HBM.  Checked through the Python mirror's MFCC vectors (their own parity is
+    test_mfcc_gpu.py's business) scored by the oracle."""
+    import gmm_cases as gc
+    import jeicyboodsp_amd
+    exe = os.path.join(ROOT, "examples", "mfcc_gmm_pipeline")
+    if not os.path.exists(exe):
+        import __graft_entry__ as ge
+        ge.build_examples()
+    rng = np.random.default_rng(91)
+    utt_blocks, n_utts = 9, 5
+    pcm = np.clip(np.rint(rng.normal(0, 3000, 512 * utt_blocks * n_utts)), -32768, 32767).astype(np.int16)
+    classes = gc.gmm_records(92, 7)
+    classes["mean"] *= 4.0
+    classes["covariance"] *= 30.0
+    pcm.tofile(tmp_path / "pcm.raw")
+    classes.tofile(tmp_path / "params.bin")
+    out = subprocess.run([exe, str(tmp_path / "pcm.raw"), str(tmp_path / "params.bin"), "7", str(utt_blocks)],
+                         check=True, stdout=subprocess.PIPE, timeout=300).stdout.decode().splitlines()
+    assert len(out) == n_utts
+    eng = jeicyboodsp_amd.Engine(0)
+    m = eng.mfcc()
+    for u, line in enumerate(out):
+        tok = line.split()
+        feats = m.frames(pcm[512 * utt_blocks * u: 512 * utt_blocks * (u + 1)])       # utt_blocks - 1 frames
+        want, arg = oracle.gmm_classify(feats, classes)
+        got = np.array([float(t) for t in tok[2:]])
+        assert int(tok[0]) == u and int(tok[1]) == arg + 1
+        assert np.all(np.abs(got - want) <= 1e-12 * np.abs(want))
+    m.close()
+    eng.close()
