@@ -44,7 +44,8 @@ int jdsp_fastconv_create(jdsp_ctx *ctx, const double *taps, int n_taps, int n_fi
     }
     if (e != hipSuccess) rc = fail(ctx, JDSP_EHIP, "jdsp_fastconv_create: alloc", e);
     if (!rc) rc = jdsp_fft_process_f64_dev(ctx, d_h, d_H, n_fft, n_filters, 1);
-    if (!rc && jdsp::launch_spectrum_to_f32(ctx->stream, (const double2 *)d_H, h->H, (long)n))
+    if (!rc && jdsp::launch_spectrum_to_f32(ctx->stream, (const double2 *)d_H, h->H, (long)n,
+                                            n_fft == 1024 ? 1.0f / 2048.0f : 1.0f))   // 1024: the kernel's 1/2 and 1/1024
         rc = fail(ctx, JDSP_EHIP, "spectrum_to_f32 launch", hipGetLastError());
     if (!rc && (e = hipStreamSynchronize(ctx->stream)) != hipSuccess) rc = fail(ctx, JDSP_EHIP, "jdsp_fastconv_create: sync", e);
     if (d_h) (void)hipFree(d_h);

@@ -23,10 +23,10 @@ __device__ __forceinline__ float conv_sample(const ConvStream &s, long pos)
     return h >= 0 ? (float)s.hist[h] : 0.f;
 }
 
-__global__ void spectrum_to_f32_kernel(const double2 *__restrict__ in, float2 *__restrict__ out, long n)
+__global__ void spectrum_to_f32_kernel(const double2 *__restrict__ in, float2 *__restrict__ out, long n, float scale)
 {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = make_float2((float)in[i].x, (float)in[i].y);
+    if (i < n) out[i] = make_float2(scale * (float)in[i].x, scale * (float)in[i].y);   // scale: a power of two, exact
 }
 
 __global__ void conv_hist_update_kernel(ConvStream s, short *__restrict__ hist_out)
@@ -81,14 +81,15 @@ __global__ __launch_bounds__(64) void fastconv1024_kernel(ConvStream s, long n_o
     if (end - 1024 >= 0 && end <= s.n_samples && end - 1024 + s.global0 >= s.valid_from) {
         const short *src = s.pcm + (end - 1024) + 2 * lane;
 #pragma unroll
-        for (int r = 0; r < 8; r++) v[r] = make_float2(0.5f * (float)src[128 * r], 0.5f * (float)src[128 * r + 1]);
+        for (int r = 0; r < 8; r++) v[r] = make_float2((float)src[128 * r], (float)src[128 * r + 1]);
     } else {
 #pragma unroll
         for (int r = 0; r < 8; r++) {
             const long p0 = end - 1024 + 2 * lane + 128 * r;
-            v[r] = make_float2(0.5f * conv_sample(s, p0), 0.5f * conv_sample(s, p0 + 1));   // 0.5: split convention
+            v[r] = make_float2(conv_sample(s, p0), conv_sample(s, p0 + 1));
         }
     }
+    // the split's 1/2 and the inverse transform's 1/1024 (:156) are folded into H (a power of two: exact)
     wave_fft512<false>(v, lds, lane, tw);
     store_natural_image(spec, lane, v);
     wave_lds_fence();
@@ -115,14 +116,22 @@ __global__ __launch_bounds__(64) void fastconv1024_kernel(ConvStream s, long n_o
         float *pc = precast ? precast + (size_t)f * plane + e * block : nullptr;
         float *ys = reinterpret_cast<float *>(lds);                  // 1024 floats fit the wave's scratch
 #pragma unroll
-        for (int d = 0; d < 8; d++)
-            *reinterpret_cast<float2 *>(ys + 2 * lane + 128 * d) = make_float2(y[d].x * (1.0f / 1024.0f), y[d].y * (1.0f / 1024.0f));
+        for (int d = 0; d < 8; d++) *reinterpret_cast<float2 *>(ys + 2 * lane + 128 * d) = y[d];
         wave_lds_fence();
-        for (int i = lane; i < block; i += 64) {
-            const float a = ys[i + n_taps - 1];
-            o[i] = (short)cast_i16_bits(a);
-            if (pc) pc[i] = a;
+        // the kept samples leave as dwords (two samples) wherever the output address allows, with a single
+        // 16-bit store at an odd head and an odd tail
+        const int head = (int)((reinterpret_cast<uintptr_t>(o) >> 1) & 1);
+        const int n_pairs = (block - head) >> 1;
+        const float *yk = ys + n_taps - 1;
+        if (lane == 0 && head) o[0] = (short)cast_i16_bits(yk[0]);
+        if (lane == 1 && ((block - head) & 1)) o[block - 1] = (short)cast_i16_bits(yk[block - 1]);
+        unsigned int *o32 = reinterpret_cast<unsigned int *>(o + head);
+        for (int p = lane; p < n_pairs; p += 64) {
+            const int i = head + 2 * p;
+            o32[p] = cast_i16_bits(yk[i]) | (cast_i16_bits(yk[i + 1]) << 16);
         }
+        if (pc)
+            for (int i = lane; i < block; i += 64) pc[i] = yk[i];
         wave_lds_fence();
     }
 }
@@ -257,9 +266,9 @@ __global__ __launch_bounds__(512, JDSP_CONV8192_MINWAVES) void fastconv8192_kern
 }
 
 // ---------------------------------------------------------------------------------------
-int launch_spectrum_to_f32(hipStream_t s, const double2 *in, float2 *out, long n)
+int launch_spectrum_to_f32(hipStream_t s, const double2 *in, float2 *out, long n, float scale)
 {
-    hipLaunchKernelGGL(spectrum_to_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, out, n);
+    hipLaunchKernelGGL(spectrum_to_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, out, n, scale);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

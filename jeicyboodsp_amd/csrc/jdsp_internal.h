@@ -143,7 +143,7 @@ struct ConvStream {
     int hist_len;
 };
 
-int launch_spectrum_to_f32(hipStream_t s, const double2 *in, float2 *out, long n);
+int launch_spectrum_to_f32(hipStream_t s, const double2 *in, float2 *out, long n, float scale);
 int launch_fastconv(hipStream_t st, int n_fft, const ConvStream &s, long n_out_blocks, int first_block, int block,
                     int n_taps, int n_filters, const float2 *H, const float2 *table, const float2 *tw4096,
                     const float2 *tw8192, short *out, float *precast, long plane, short *hist_out);
