@@ -134,12 +134,189 @@ __global__ __launch_bounds__(64) void mfcc_kernel(const short *__restrict__ pcm,
     }
 }
 
+
+// ---- two frames per wavefront, in lock-step --------------------------------------------------------------
+// The one-frame kernel spends 65 % of its wave cycles waiting (profiles/r01_chains_sq_counters.csv): a serial
+// chain of short phases separated by LDS fences and table loads, at about five waves per SIMD.  Here a wave
+// carries two frames through every phase together: the table loads are shared, every fence covers two
+// frames, and two independent dependency chains interleave.  |X| goes through registers and reuses the
+// transform scratch, which keeps the LDS footprint at 9.8 KB per wave (four waves per SIMD).
+__device__ __forceinline__ void mfcc_load_frame(const short *__restrict__ src, const MfccDev &p, int lane, float2 (&v)[8])
+{
+    // x[i] = s[i] - preemph * s[i-1] for 1 <= i < win_len, x[0] = 0 (:208 starts at i = 1), zero beyond
+    if (p.win_len == 1024 && (((uintptr_t)src) & 3u) == 0) {
+        const unsigned int *s32 = reinterpret_cast<const unsigned int *>(src) + lane;
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const float2 cur = unpack_i16x2(s32[64 * r]);
+            const bool first = (lane == 0 && r == 0);
+            const float sm = first ? 0.f : (float)((int)s32[first ? 0 : 64 * r - 1] >> 16);
+            const float2 w = p.window[lane + 64 * r];
+            const float x0 = first ? 0.f : cur.x - p.preemph * sm;
+            const float x1 = cur.y - p.preemph * cur.x;
+            v[r] = make_float2(x0 * w.x, x1 * w.y);
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const int i0 = 2 * lane + 128 * r;
+            float sm = 0.f, s0 = 0.f, s1 = 0.f;
+            if (i0 >= 1 && i0 - 1 < p.win_len) sm = (float)src[i0 - 1];
+            if (i0 < p.win_len) s0 = (float)src[i0];
+            if (i0 + 1 < p.win_len) s1 = (float)src[i0 + 1];
+            const float2 w = p.window[lane + 64 * r];            // halved Hamming pair, zero beyond win_len
+            const float x0 = (i0 >= 1) ? s0 - p.preemph * sm : 0.f;
+            const float x1 = s1 - p.preemph * s0;
+            v[r] = make_float2(x0 * w.x, x1 * w.y);
+        }
+    }
+}
+
+// |X[m]|, m = 128 j + 2 lane + e < 512, of the natural-order image `img` (:218-220)
+__device__ __forceinline__ void mfcc_magnitudes(const float2 *img, int lane, float2 wsp0, float2 wsp1, float2 (&amp)[4])
+{
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int m = 128 * j + 2 * lane;
+        const float4 zz = *reinterpret_cast<const float4 *>(&img[m]);
+        float2 zr0, zr1;
+        load_mirror_pair(img, m, zr0, zr1);
+        float2 lo0, hi0, lo1, hi1;
+        if (j == 0) { split_fwd<0>(make_float2(zz.x, zz.y), zr0, wsp0, lo0, hi0); split_fwd<0>(make_float2(zz.z, zz.w), zr1, wsp1, lo1, hi1); }
+        if (j == 1) { split_fwd<1>(make_float2(zz.x, zz.y), zr0, wsp0, lo0, hi0); split_fwd<1>(make_float2(zz.z, zz.w), zr1, wsp1, lo1, hi1); }
+        if (j == 2) { split_fwd<2>(make_float2(zz.x, zz.y), zr0, wsp0, lo0, hi0); split_fwd<2>(make_float2(zz.z, zz.w), zr1, wsp1, lo1, hi1); }
+        if (j == 3) { split_fwd<3>(make_float2(zz.x, zz.y), zr0, wsp0, lo0, hi0); split_fwd<3>(make_float2(zz.z, zz.w), zr1, wsp1, lo1, hi1); }
+        amp[j] = make_float2(__builtin_amdgcn_sqrtf(lo0.x * lo0.x + lo0.y * lo0.y),
+                             __builtin_amdgcn_sqrtf(lo1.x * lo1.x + lo1.y * lo1.y));
+    }
+}
+
+// mel filterbank (:157-168) of one frame: `mag` -> channel sums in `logmel` (LDS atomics, see mfcc_kernel)
+__device__ __forceinline__ void mfcc_mel(const float *mag, float *logmel, const MfccDev &p, int lane, const float (&ff)[8],
+                                         const int (&kk)[8])
+{
+    const int i0 = 8 * lane;
+    if (i0 >= p.n_bins) return;
+    const float4 m0 = *reinterpret_cast<const float4 *>(&mag[i0]), m1 = *reinterpret_cast<const float4 *>(&mag[i0 + 4]);
+    const float mm[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
+    int cur = kk[0];
+    float lo = 0.f, hi = 0.f;
+#pragma unroll
+    for (int t = 0; t < 8; t++) {
+        if (kk[t] != cur) {
+            if (cur >= 1) atomicAdd(&logmel[cur - 1], lo);
+            if (cur < p.n_chan) atomicAdd(&logmel[cur], hi);
+            cur = kk[t];
+            lo = hi = 0.f;
+        }
+        if (cur == 0) hi += (1.f - ff[t]) * mm[t];                 // :161
+        else {
+            lo += ff[t] * mm[t];                                   // :164
+            if (cur != p.n_chan) hi += (1.f - ff[t]) * mm[t];      // :165-166
+        }
+    }
+    if (cur >= 1) atomicAdd(&logmel[cur - 1], lo);
+    if (cur < p.n_chan) atomicAdd(&logmel[cur], hi);
+}
+
+__global__ __launch_bounds__(64) void mfcc_x2_kernel(const short *__restrict__ pcm, const long long *__restrict__ starts,
+                                                     long n_frames, MfccDev p, const float2 *__restrict__ table,
+                                                     double *__restrict__ feats)
+{
+    __shared__ __attribute__((aligned(16))) float2 lds[2][kWaveLdsComplex];
+    __shared__ float logmel[2][64];
+    const int lane = threadIdx.x;
+    const long per_xcd = (gridDim.x + 7) >> 3;
+    const long fa = ((long)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3)) * 2;
+    if (fa >= n_frames) return;
+    const bool two = fa + 1 < n_frames;
+    const long fb = two ? fa + 1 : fa;                               // odd tail: the second slot repeats the first
+    float2 va[8], vb[8];
+    mfcc_load_frame(pcm + (starts ? starts[fa] : (long long)p.hop * fa), p, lane, va);
+    mfcc_load_frame(pcm + (starts ? starts[fb] : (long long)p.hop * fb), p, lane, vb);
+    WaveTwiddles tw;
+    load_wave_twiddles(tw, table, lane);
+    const float2 wsp0 = table[kStftSplit + 2 * lane];
+    const float2 wsp1 = table[kStftSplit + 2 * lane + 1];
+
+    wave_fft512_x2<false>(va, vb, lds[0], lds[1], lane, tw);
+    store_natural_image(lds[0], lane, va);
+    store_natural_image(lds[1], lane, vb);
+    logmel[0][lane] = 0.f;
+    logmel[1][lane] = 0.f;
+    wave_lds_fence();
+    float2 amp_a[4], amp_b[4];
+    mfcc_magnitudes(lds[0], lane, wsp0, wsp1, amp_a);
+    mfcc_magnitudes(lds[1], lane, wsp0, wsp1, amp_b);
+    wave_lds_fence();                                                // every lane's split reads are done: overwrite
+    float *mag_a = reinterpret_cast<float *>(lds[0]), *mag_b = reinterpret_cast<float *>(lds[1]);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int m = 128 * j + 2 * lane;
+        if (p.bin_stride == 1) {
+            *reinterpret_cast<float2 *>(&mag_a[m]) = amp_a[j];
+            *reinterpret_cast<float2 *>(&mag_b[m]) = amp_b[j];
+        } else {                                                     // 512-point bins = even 1024-point bins
+            mag_a[m >> 1] = amp_a[j].x;
+            mag_b[m >> 1] = amp_b[j].x;
+        }
+    }
+    wave_lds_fence();
+    {
+        const int i0 = 8 * lane;
+        float ff[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int kk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (i0 < p.n_bins) {
+            const float4 f0 = *reinterpret_cast<const float4 *>(p.mel_fb + i0), f1 = *reinterpret_cast<const float4 *>(p.mel_fb + i0 + 4);
+            const int4 k0 = *reinterpret_cast<const int4 *>(p.mel_k + i0), k1 = *reinterpret_cast<const int4 *>(p.mel_k + i0 + 4);
+            ff[0] = f0.x; ff[1] = f0.y; ff[2] = f0.z; ff[3] = f0.w; ff[4] = f1.x; ff[5] = f1.y; ff[6] = f1.z; ff[7] = f1.w;
+            kk[0] = k0.x; kk[1] = k0.y; kk[2] = k0.z; kk[3] = k0.w; kk[4] = k1.x; kk[5] = k1.y; kk[6] = k1.z; kk[7] = k1.w;
+        }
+        mfcc_mel(mag_a, logmel[0], p, lane, ff, kk);
+        mfcc_mel(mag_b, logmel[1], p, lane, ff, kk);
+    }
+    wave_lds_fence();
+    if (lane < p.n_chan) {
+        logmel[0][lane] = logf(logmel[0][lane]);                     // :171
+        logmel[1][lane] = logf(logmel[1][lane]);
+    }
+    wave_lds_fence();
+    // DCT-II (:178-182) and lifter (:189), both frames off one pass over the table
+    {
+        const int i = lane & 15, part = lane >> 4;
+        double acc_a = 0.0, acc_b = 0.0;
+        if (i < p.n_cep) {
+#pragma unroll 4
+            for (int k = part; k < p.n_chan; k += 4) {
+                const double c = p.dct[k * 32 + i];
+                acc_a += c * (double)logmel[0][k];
+                acc_b += c * (double)logmel[1][k];
+            }
+        }
+        acc_a += __shfl_xor(acc_a, 16); acc_b += __shfl_xor(acc_b, 16);
+        acc_a += __shfl_xor(acc_a, 32); acc_b += __shfl_xor(acc_b, 32);
+        if (lane < p.n_cep) {
+            const double lw = p.lifter_w[lane];
+            feats[fa * p.n_cep + lane] = acc_a * lw;
+            if (two) feats[fb * p.n_cep + lane] = acc_b * lw;
+        }
+    }
+}
+
 int launch_mfcc(hipStream_t s, const short *pcm, const long long *starts, long n_frames, const MfccDev &p,
                 const float2 *table, double *feats)
 {
     if (n_frames <= 0) return 0;
+#ifndef JDSP_MFCC_X2
+#define JDSP_MFCC_X2 1             // 1: two frames per wavefront in lock-step (mfcc_x2_kernel); 0: one frame per wavefront
+#endif
+#if JDSP_MFCC_X2
+    long grid = ((n_frames + 1) / 2 + 7) / 8 * 8;
+    hipLaunchKernelGGL(mfcc_x2_kernel, dim3((unsigned)grid), dim3(64), 0, s, pcm, starts, n_frames, p, table, feats);
+#else
     long grid = (n_frames + 7) / 8 * 8;
     hipLaunchKernelGGL(mfcc_kernel, dim3((unsigned)grid), dim3(64), 0, s, pcm, starts, n_frames, p, table, feats);
+#endif
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

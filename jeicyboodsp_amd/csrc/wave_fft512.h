@@ -182,4 +182,50 @@ __device__ __forceinline__ void wave_fft512(float2 (&v)[8], float2 *lds, int lan
     dft8<INV>(v);
 }
 
+// Two independent transforms in one wave, stage by stage: the same passes as wave_fft512 with both frames'
+// LDS exchanges issued together, so each fence covers two transforms and the scheduler has two independent
+// dependency chains to interleave.  `lds_a` / `lds_b`: two scratch regions of kWaveLdsComplex elements.
+template <bool INV>
+__device__ __forceinline__ void wave_fft512_x2(float2 (&a)[8], float2 (&b)[8], float2 *lds_a, float2 *lds_b, int lane,
+                                               const WaveTwiddles &tw)
+{
+    dft8<INV>(a);
+    dft8<INV>(b);
+#pragma unroll
+    for (int k = 1; k < 8; k++) {
+        a[k] = INV ? cmul_conj(a[k], tw.t1[k - 1]) : cmul(a[k], tw.t1[k - 1]);
+        b[k] = INV ? cmul_conj(b[k], tw.t1[k - 1]) : cmul(b[k], tw.t1[k - 1]);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++) { lds_a[k * 72 + lane] = a[k]; lds_b[k * 72 + lane] = b[k]; }
+    wave_lds_fence();
+    {
+        const int base = (lane >> 3) * 72 + (lane & 7);
+#pragma unroll
+        for (int q = 0; q < 8; q++) { a[q] = lds_a[base + 8 * q]; b[q] = lds_b[base + 8 * q]; }
+    }
+    wave_lds_fence();
+    dft8<INV>(a);
+    dft8<INV>(b);
+#pragma unroll
+    for (int c = 1; c < 8; c++) {
+        a[c] = INV ? cmul_conj(a[c], tw.t2[c - 1]) : cmul(a[c], tw.t2[c - 1]);
+        b[c] = INV ? cmul_conj(b[c], tw.t2[c - 1]) : cmul(b[c], tw.t2[c - 1]);
+    }
+    {
+        const int base = (lane >> 3) * 73 + (lane & 7);
+#pragma unroll
+        for (int c = 0; c < 8; c++) { lds_a[base + 8 * c] = a[c]; lds_b[base + 8 * c] = b[c]; }
+    }
+    wave_lds_fence();
+    {
+        const int base = (lane & 7) * 73 + (lane >> 3) * 8;
+#pragma unroll
+        for (int q = 0; q < 8; q++) { a[q] = lds_a[base + q]; b[q] = lds_b[base + q]; }
+    }
+    wave_lds_fence();
+    dft8<INV>(a);
+    dft8<INV>(b);
+}
+
 }  // namespace jdsp
