@@ -73,6 +73,11 @@ struct MfccDev {
     const float2 *window;        // [512] halved Hamming pairs over win_len, zero beyond
     const float *mel_fb;         // [512] rgdFilterBank as float (zero beyond n_bins)
     const int *mel_k;            // [512] rgdFiBins
+    // lane-per-index form of the same filterbank (mfcc_x2_kernel): lane L sums the bins [seg[L].x, +seg[L].y)
+    // (at most 16, all with rgdFiBins value seg[L].z) with weights seg_w[t * 64 + L]; seg_ok = it fits 64 lanes
+    const int4 *seg;
+    const float *seg_w;
+    int seg_ok;
     const double *dct;           // [n_chan][32]: sqrt(2/C) cos(PI i (k-0.5)/C)
     const double *lifter_w;      // [32]: 1 + L/2 sin(PI i / L)
 };

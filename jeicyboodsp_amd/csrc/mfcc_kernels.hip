@@ -122,13 +122,16 @@ __global__ __launch_bounds__(64) void mfcc_kernel(const short *__restrict__ pcm,
     // DCT-II (:178-182) and lifter (:189): cepstrum i on lanes i, i+16, i+32, i+48, each summing every
     // fourth channel (four short independent chains of table loads instead of one long one)
     {
-        const int i = lane & 15, part = lane >> 4;
+        // up to 16 cepstra: four lane groups each sum every fourth channel; 17..32: two groups, every second
+        const bool wide = p.n_cep > 16;
+        const int i = wide ? (lane & 31) : (lane & 15), part = wide ? (lane >> 5) : (lane >> 4), step = wide ? 2 : 4;
         double acc = 0.0;
         if (i < p.n_cep) {
 #pragma unroll 4
-            for (int k = part; k < p.n_chan; k += 4) acc += p.dct[k * 32 + i] * (double)logmel[k];
+            for (int k = part; k < p.n_chan; k += step) acc += p.dct[k * 32 + i] * (double)logmel[k];
         }
-        acc += __shfl_xor(acc, 16);
+        const double other = __shfl_xor(acc, 16);
+        if (!wide) acc += other;
         acc += __shfl_xor(acc, 32);
         if (lane < p.n_cep) feats[f * p.n_cep + lane] = acc * p.lifter_w[lane];
     }
@@ -238,6 +241,11 @@ __global__ __launch_bounds__(64) void mfcc_x2_kernel(const short *__restrict__ p
     load_wave_twiddles(tw, table, lane);
     const float2 wsp0 = table[kStftSplit + 2 * lane];
     const float2 wsp1 = table[kStftSplit + 2 * lane + 1];
+    // this lane's piece of the filterbank: bins [sg.x, sg.x + sg.y) of channel index sg.z, weights sw[t]
+    const int4 sg = p.seg[lane];
+    float sw[16];
+#pragma unroll
+    for (int t = 0; t < 16; t++) sw[t] = p.seg_w[t * 64 + lane];
 
     wave_fft512_x2<false>(va, vb, lds[0], lds[1], lane, tw);
     store_natural_image(lds[0], lane, va);
@@ -262,18 +270,24 @@ __global__ __launch_bounds__(64) void mfcc_x2_kernel(const short *__restrict__ p
         }
     }
     wave_lds_fence();
+    // mel filterbank (:157-168), one channel index per lane: bin i of index k adds f_i m_i to channel k - 1 and
+    // (1 - f_i) m_i to channel k, so a lane whose bins all share k sums both in registers and issues exactly two
+    // LDS atomics.  (Walking 8 consecutive bins per lane and flushing whenever the index changed took ~18
+    // atomic instructions per frame, ~32 LDS cycles each: the LDS pipe was busy 72 % of the kernel.)
     {
-        const int i0 = 8 * lane;
-        float ff[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        int kk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (i0 < p.n_bins) {
-            const float4 f0 = *reinterpret_cast<const float4 *>(p.mel_fb + i0), f1 = *reinterpret_cast<const float4 *>(p.mel_fb + i0 + 4);
-            const int4 k0 = *reinterpret_cast<const int4 *>(p.mel_k + i0), k1 = *reinterpret_cast<const int4 *>(p.mel_k + i0 + 4);
-            ff[0] = f0.x; ff[1] = f0.y; ff[2] = f0.z; ff[3] = f0.w; ff[4] = f1.x; ff[5] = f1.y; ff[6] = f1.z; ff[7] = f1.w;
-            kk[0] = k0.x; kk[1] = k0.y; kk[2] = k0.z; kk[3] = k0.w; kk[4] = k1.x; kk[5] = k1.y; kk[6] = k1.z; kk[7] = k1.w;
+        float lo_a = 0.f, hi_a = 0.f, lo_b = 0.f, hi_b = 0.f;
+#pragma unroll
+        for (int t = 0; t < 16; t++) {
+            const bool on = t < sg.y;
+            const int bin = on ? sg.x + t : 0;
+            const float ma = on ? mag_a[bin] : 0.f, mb = on ? mag_b[bin] : 0.f;
+            lo_a = fmaf(sw[t], ma, lo_a); hi_a += fmaf(-sw[t], ma, ma);       // :164 / :161,:165-166
+            lo_b = fmaf(sw[t], mb, lo_b); hi_b += fmaf(-sw[t], mb, mb);
         }
-        mfcc_mel(mag_a, logmel[0], p, lane, ff, kk);
-        mfcc_mel(mag_b, logmel[1], p, lane, ff, kk);
+        if (sg.y > 0) {
+            if (sg.z >= 1) { atomicAdd(&logmel[0][sg.z - 1], lo_a); atomicAdd(&logmel[1][sg.z - 1], lo_b); }
+            if (sg.z < p.n_chan) { atomicAdd(&logmel[0][sg.z], hi_a); atomicAdd(&logmel[1][sg.z], hi_b); }
+        }
     }
     wave_lds_fence();
     if (lane < p.n_chan) {
@@ -283,17 +297,19 @@ __global__ __launch_bounds__(64) void mfcc_x2_kernel(const short *__restrict__ p
     wave_lds_fence();
     // DCT-II (:178-182) and lifter (:189), both frames off one pass over the table
     {
-        const int i = lane & 15, part = lane >> 4;
+        const bool wide = p.n_cep > 16;                              // see mfcc_kernel
+        const int i = wide ? (lane & 31) : (lane & 15), part = wide ? (lane >> 5) : (lane >> 4), step = wide ? 2 : 4;
         double acc_a = 0.0, acc_b = 0.0;
         if (i < p.n_cep) {
 #pragma unroll 4
-            for (int k = part; k < p.n_chan; k += 4) {
+            for (int k = part; k < p.n_chan; k += step) {
                 const double c = p.dct[k * 32 + i];
                 acc_a += c * (double)logmel[0][k];
                 acc_b += c * (double)logmel[1][k];
             }
         }
-        acc_a += __shfl_xor(acc_a, 16); acc_b += __shfl_xor(acc_b, 16);
+        const double oa = __shfl_xor(acc_a, 16), ob = __shfl_xor(acc_b, 16);
+        if (!wide) { acc_a += oa; acc_b += ob; }
         acc_a += __shfl_xor(acc_a, 32); acc_b += __shfl_xor(acc_b, 32);
         if (lane < p.n_cep) {
             const double lw = p.lifter_w[lane];
@@ -310,13 +326,13 @@ int launch_mfcc(hipStream_t s, const short *pcm, const long long *starts, long n
 #ifndef JDSP_MFCC_X2
 #define JDSP_MFCC_X2 1             // 1: two frames per wavefront in lock-step (mfcc_x2_kernel); 0: one frame per wavefront
 #endif
-#if JDSP_MFCC_X2
-    long grid = ((n_frames + 1) / 2 + 7) / 8 * 8;
-    hipLaunchKernelGGL(mfcc_x2_kernel, dim3((unsigned)grid), dim3(64), 0, s, pcm, starts, n_frames, p, table, feats);
-#else
-    long grid = (n_frames + 7) / 8 * 8;
-    hipLaunchKernelGGL(mfcc_kernel, dim3((unsigned)grid), dim3(64), 0, s, pcm, starts, n_frames, p, table, feats);
-#endif
+    if (JDSP_MFCC_X2 && p.seg_ok) {
+        const long grid = ((n_frames + 1) / 2 + 7) / 8 * 8;
+        hipLaunchKernelGGL(mfcc_x2_kernel, dim3((unsigned)grid), dim3(64), 0, s, pcm, starts, n_frames, p, table, feats);
+    } else {                              // filterbanks that do not fit one piece per lane (many narrow channels)
+        const long grid = (n_frames + 7) / 8 * 8;
+        hipLaunchKernelGGL(mfcc_kernel, dim3((unsigned)grid), dim3(64), 0, s, pcm, starts, n_frames, p, table, feats);
+    }
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

@@ -110,3 +110,23 @@ def test_silent_frame_gives_minus_inf_like_reference(eng, oracle):
     got = m.frames(pcm)
     assert np.array_equal(np.isfinite(got), np.isfinite(want)) and not np.isfinite(got).any()
     m.close()
+
+
+@pytest.mark.parametrize("kw,n_bins", [
+    (dict(n_chan=64, n_cep=20), 512),                                   # 65 channel indices: more pieces than lanes,
+    (dict(win_len=512, hop=256, n_fft=512, n_chan=64, n_cep=13, half_rate=8000.0), 256),   # the one-frame kernel runs
+    (dict(n_chan=12, n_cep=12), 512),                                   # wide channels: several 16-bin pieces each
+    (dict(n_chan=1, n_cep=1), 512),
+])
+def test_filterbank_shapes_and_odd_frame_counts(eng, oracle, kw, n_bins):
+    """Both MFCC kernels (two frames per wave with one filterbank piece per lane; one frame per wave when the
+    pieces do not fit 64 lanes) and frame counts that leave the last wave half empty."""
+    ocfg = oracle.mfcc_cfg(n_bins=n_bins, **kw)
+    m = eng.mfcc(**kw)
+    win, hop = m.cfg.win_len, m.cfg.hop
+    for nf in (1, 2, 7):
+        pcm = _pcm(40 + nf, win + hop * (nf - 1))
+        got = m.frames(pcm)
+        assert got.shape == (nf, m.cfg.n_cep)
+        _check(got, oracle.mfcc_frames(ocfg, pcm, nf))
+    m.close()
