@@ -426,10 +426,16 @@ __global__ __launch_bounds__(64) void fastconv_upols_kernel(const float2 *__rest
 // kUpolsK * P), with the next row in flight while the current one is used, and the partition spectra sit in
 // LDS, loaded once per workgroup.  (One wave per sub-block reading P rows and P partition spectra from L2
 // ran at 22 TB/s of L2 traffic: 44 us for the native shape; profiles/r01_fastconv_partitioned.txt.)
-constexpr int kUpolsK = 4;
-constexpr int kUpolsDepth = 4;
+#ifndef JDSP_UPOLS_SHAPE
+#define JDSP_UPOLS_SHAPE 1        // 0: 4 waves x 4 outputs, 4 rows in flight (2 waves/SIMD); 1: 16 waves x 2 outputs, 2 rows
+#endif                            //    in flight (4 waves/SIMD: the workgroup fills a CU, LDS = 60 KB of spectra + 73 KB scratch)
+#if JDSP_UPOLS_SHAPE
+constexpr int kUpolsWaves = 16, kUpolsK = 2, kUpolsDepth = 2;
+#else
+constexpr int kUpolsWaves = 4, kUpolsK = 4, kUpolsDepth = 4;
+#endif
 
-__global__ __launch_bounds__(256) void fastconv_upols4_kernel(const float2 *__restrict__ X, const float2 *__restrict__ Hp,
+__global__ __launch_bounds__(kUpolsWaves * 64) void fastconv_upols4_kernel(const float2 *__restrict__ X, const float2 *__restrict__ Hp,
                                                               int n_part, int n_filters, long first_row, long n_sub,
                                                               long max_row, const float2 *__restrict__ table,
                                                               short *__restrict__ out, float *__restrict__ precast,
@@ -441,13 +447,13 @@ __global__ __launch_bounds__(256) void fastconv_upols4_kernel(const float2 *__re
     float2 *lds = smem + (size_t)n_part * kUpolsPitch + (size_t)wave * kWaveLdsComplex;   // this wave's scratch
     const long per_xcd = (gridDim.x + 7) >> 3;
     const long wg = (long)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    const long t0 = (wg * 4 + wave) * kUpolsK;
+    const long t0 = (wg * kUpolsWaves + wave) * kUpolsK;
     const bool live = t0 < n_sub;
     for (int f = 0; f < n_filters; f++) {
         {
             const float4 *src = reinterpret_cast<const float4 *>(Hp + (size_t)f * n_part * kUpolsPitch);
             float4 *dst = reinterpret_cast<float4 *>(Hs);
-            for (int i = threadIdx.x; i < n_part * (kUpolsPitch / 2); i += 256) dst[i] = src[i];
+            for (int i = threadIdx.x; i < n_part * (kUpolsPitch / 2); i += kUpolsWaves * 64) dst[i] = src[i];
         }
         __syncthreads();
         if (live) {
@@ -579,17 +585,17 @@ int launch_fastconv_upols(hipStream_t st, const ConvStream &s, long n_out_blocks
         hipLaunchKernelGGL(fastconv_upols_kernel, dim3((unsigned)grid), dim3(64), 0, st, X, Hp, n_part, n_filters, first_row,
                            n_sub, rect_table, out, precast, plane);
 #else
-        const long per_wg = 4 * kUpolsK;
+        const long per_wg = kUpolsWaves * kUpolsK;
         const long grid = ((n_sub + per_wg - 1) / per_wg + 7) / 8 * 8;
-        const size_t lds = ((size_t)n_part * kUpolsPitch + 4 * (size_t)kWaveLdsComplex) * sizeof(float2);
+        const size_t lds = ((size_t)n_part * kUpolsPitch + kUpolsWaves * (size_t)kWaveLdsComplex) * sizeof(float2);
         static bool attr_set = false;
         if (!attr_set) {
             if (hipFuncSetAttribute((const void *)fastconv_upols4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)((16 * (size_t)kUpolsPitch + 4 * (size_t)kWaveLdsComplex) * sizeof(float2))) != hipSuccess)
+                                    (int)((16 * (size_t)kUpolsPitch + kUpolsWaves * (size_t)kWaveLdsComplex) * sizeof(float2))) != hipSuccess)
                 return -1;
             attr_set = true;
         }
-        hipLaunchKernelGGL(fastconv_upols4_kernel, dim3((unsigned)grid), dim3(256), lds, st, X, Hp, n_part, n_filters,
+        hipLaunchKernelGGL(fastconv_upols4_kernel, dim3((unsigned)grid), dim3(kUpolsWaves * 64), lds, st, X, Hp, n_part, n_filters,
                            first_row, n_sub, n_frames - 1, rect_table, out, precast, plane);
 #endif
     }
