@@ -350,6 +350,8 @@ typedef struct jdsp_hmm jdsp_hmm;
 /* models: n_models (1..1024) six-state records; log(transProb) is taken here, on the host (Viterbi:196). */
 int jdsp_hmm_create(jdsp_ctx *ctx, const jdsp_hmm_param *models, int n_models, jdsp_hmm **out);
 int jdsp_hmm_destroy(jdsp_hmm *h);
+/* "evaluation": 0 (default) / 1, as jdsp_gmm_set_option, for the state densities. */
+int jdsp_hmm_set_option(jdsp_hmm *h, const char *name, long value);
 /* Sizes the emission scratch (n_frames * n_models * 6 doubles) ahead of time, e.g. before a graph capture. */
 int jdsp_hmm_reserve(jdsp_hmm *h, long n_frames);
 /* HMMRecognition() (Viterbi:157-246) as the reference computes it, quirks included (see

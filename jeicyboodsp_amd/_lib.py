@@ -76,6 +76,7 @@ def _load():
         "jdsp_gmm_score": (i, [vp, vp, vp, l, vp, vp]),
         "jdsp_hmm_create": (i, [vp, vp, i, C.POINTER(vp)]),
         "jdsp_hmm_destroy": (i, [vp]),
+        "jdsp_hmm_set_option": (i, [vp, C.c_char_p, l]),
         "jdsp_hmm_reserve": (i, [vp, l]),
         "jdsp_hmm_viterbi_dev": (i, [vp, vp, l, vp, l, vp, vp, vp, vp]),
         "jdsp_hmm_viterbi": (i, [vp, vp, vp, l, vp, vp, vp, vp]),

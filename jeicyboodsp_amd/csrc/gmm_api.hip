@@ -189,6 +189,17 @@ int jdsp_hmm_destroy(jdsp_hmm *h)
     return JDSP_OK;
 }
 
+int jdsp_hmm_set_option(jdsp_hmm *h, const char *name, long value)
+{
+    if (!h || !name) return JDSP_EINVAL;
+    if (!strcmp(name, "evaluation")) {
+        if (value != 0 && value != 1) return fail(h->ctx, JDSP_EINVAL, "jdsp_hmm_set_option: evaluation is 0 or 1");
+        h->fused = (int)value;
+        return JDSP_OK;
+    }
+    return fail(h->ctx, JDSP_EINVAL, "jdsp_hmm_set_option: unknown option");
+}
+
 int jdsp_hmm_reserve(jdsp_hmm *h, long n_frames)
 {
     if (!h) return JDSP_EINVAL;
@@ -217,7 +228,7 @@ int jdsp_hmm_viterbi_dev(jdsp_hmm *h, const double *feats_dev, long n_frames, co
     JDSP_HIP(ctx, hipSetDevice(ctx->device));
     const double log_init = log(1.0 / 6.0);                                      // Viterbi:186
     if (jdsp::launch_hmm_viterbi(ctx->stream, feats_dev, n_frames, (const long long *)utt_first_dev, n_utts, h->records,
-                                 h->log_trans, h->n_models, log_init, h->emission, scores_dev, best_dev, path_dev,
+                                 h->log_trans, h->n_models, h->fused, log_init, h->emission, scores_dev, best_dev, path_dev,
                                  trellis_dev))
         return fail(ctx, JDSP_EHIP, "hmm launch", hipGetLastError());
     return JDSP_OK;

@@ -129,6 +129,7 @@ __global__ __launch_bounds__(256) void gmm_score_kernel(const double *__restrict
 }
 
 // log b[f][g] for every frame f and every state GMM g (n_g = models * 6); 64 frames x one g per wave.
+template <bool FUSED>
 __global__ __launch_bounds__(64) void gmm_emission_kernel(const double *__restrict__ feats, long n_frames,
                                                           const double *__restrict__ gmm, int n_g,
                                                           double *__restrict__ b)
@@ -138,7 +139,8 @@ __global__ __launch_bounds__(64) void gmm_emission_kernel(const double *__restri
     if (f >= n_frames) return;
     double x[12];
     load_vector(feats, f, x);
-    b[f * n_g + gi] = log(gmm_mixture(x, gmm + (size_t)gi * kGmmRecord));                          // Viterbi:186,:196
+    const double *g = gmm + (size_t)gi * kGmmRecord;
+    b[f * n_g + gi] = log(FUSED ? gmm_mixture_fused(x, g) : gmm_mixture(x, g));                     // Viterbi:186,:196
 }
 
 // Eight lanes per utterance (six used, one per state m), models in turn: the six-state recursion as the
@@ -226,13 +228,14 @@ int launch_gmm_score(hipStream_t stream, const double *feats, long n_frames, con
 }
 
 int launch_hmm_viterbi(hipStream_t stream, const double *feats, long n_frames, const long long *utt_first, long n_utts,
-                       const double *gmm, const double *log_trans, int n_models, double log_init, double *b,
+                       const double *gmm, const double *log_trans, int n_models, int fused, double log_init, double *b,
                        double *scores, int *best, int *path, double *trellis)
 {
     if (n_utts <= 0) return 0;
     if (n_frames > 0) {
-        hipLaunchKernelGGL(gmm_emission_kernel, dim3((unsigned)((n_frames + 63) / 64), (unsigned)(n_models * 6)),
-                           dim3(64), 0, stream, feats, n_frames, gmm, n_models * 6, b);
+        const dim3 grid((unsigned)((n_frames + 63) / 64), (unsigned)(n_models * 6));
+        if (fused) hipLaunchKernelGGL(gmm_emission_kernel<true>, grid, dim3(64), 0, stream, feats, n_frames, gmm, n_models * 6, b);
+        else hipLaunchKernelGGL(gmm_emission_kernel<false>, grid, dim3(64), 0, stream, feats, n_frames, gmm, n_models * 6, b);
         if (hipGetLastError() != hipSuccess) return -1;
     }
     hipLaunchKernelGGL(hmm_trellis_kernel, dim3((unsigned)((n_utts + 7) / 8)), dim3(64), 0, stream, b, utt_first,

@@ -191,7 +191,7 @@ constexpr int kGmmMaxClasses = 256;
 int launch_gmm_score(hipStream_t stream, const double *feats, long n_frames, const long long *utt_first, long n_utts,
                      const double *gmm, int n_classes, int fused, double *scores, int *best);
 int launch_hmm_viterbi(hipStream_t stream, const double *feats, long n_frames, const long long *utt_first, long n_utts,
-                       const double *gmm, const double *log_trans, int n_models, double log_init, double *b,
+                       const double *gmm, const double *log_trans, int n_models, int fused, double log_init, double *b,
                        double *scores, int *best, int *path, double *trellis);
 int launch_mfcc(hipStream_t s, const short *pcm, const long long *starts, long n_frames, const MfccDev &p,
                 const float2 *table, double *feats);
@@ -243,6 +243,7 @@ struct jdsp_gmm {
 struct jdsp_hmm {
     jdsp_ctx *ctx = nullptr;
     int n_models = 0;
+    int fused = 0;                        // "evaluation" option, as jdsp_gmm
     double *records = nullptr;            // [n_models * 6][kGmmRecord]
     double *log_trans = nullptr;          // [n_models][6][6], log() taken on the host
     double *emission = nullptr;           // scratch [frames][n_models * 6], grown on demand

@@ -446,6 +446,9 @@ class Hmm(_Child):
         self._h = h
         engine._children.append(self)
 
+    def set_option(self, name, value):
+        self.eng._ck(L.jdsp_hmm_set_option(self._h, name.encode(), int(value)))
+
     def viterbi(self, feats, utt_first, want_path=True, want_trellis=False):
         """-> (scores [n_utts, n_models], best [n_utts], path [n_models, n_vectors] or None[, trellis])."""
         n_utts = len(utt_first) - 1

@@ -171,6 +171,22 @@ def test_hmm_recursion_finite_regime(eng, oracle):
     assert np.all(scores[1] == 0.0)                                   # one vector: dTempProb keeps its initial 0
 
 
+def test_hmm_fused_evaluation_option(eng, oracle):
+    models = gc.hmm_records_finite(41, 2)
+    lens = [9, 33]
+    first = gc.offsets(lens)
+    x = np.concatenate([gc.vectors_near(50 + i, n, models["gMMParam"][i % 2, i % 6]) for i, n in enumerate(lens)])
+    h = eng.hmm(models)
+    ref = h.viterbi(x, first, want_trellis=True)
+    h.set_option("evaluation", 1)
+    got = h.viterbi(x, first, want_trellis=True)
+    fin = np.isfinite(ref[3])
+    assert fin.any() and np.array_equal(np.isfinite(got[3]), fin)
+    assert np.all(np.abs(got[3][fin] - ref[3][fin]) <= 1e-10 * np.abs(ref[3][fin]))       # trellis
+    assert np.array_equal(got[2], ref[2]) and np.array_equal(got[1], ref[1])                # states, best model
+    h.close()
+
+
 def test_hmm_recursion_nan_regime(eng, oracle):
     """Ordinary parameters: the accumulated log probability is negative and Viterbi_version1.cpp:196's
     log() of it makes the trellis NaN from the second vector on; the device path must do the same."""
