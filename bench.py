@@ -98,8 +98,8 @@ def read_traffic():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=500)
     ap.add_argument("--frames", type=int, default=FRAMES_PER_GPU, help="frames per GPU per step")
     ap.add_argument("--gather", action="store_true", help="time the RCCL all_gather of the spectra even with one rank")
     ap.add_argument("--no-gather", action="store_true", help="skip the (separately reported) output all_gather at N > 1")
@@ -137,12 +137,16 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        eng.stft(pcm, B, N_FFT, HOP, out=spec)
+    eng.stft(pcm, B, N_FFT, HOP, out=spec)            # builds the handle's constant tables (first call only)
     barrier()
     # Timed region: EXACTLY K launches, captured once into a hipGraph (jdsp_stft_i16_dev only
     # enqueues: no allocation, no sync) and replayed, so the host's per-launch overhead is not in
     # the way; bracketed by HIP events on the launch stream and by barriers for the wall clock.
+    # The capture comes BEFORE the warmup, so that the W warmup launches run right up to the barrier that
+    # opens the timed region.  The defaults (W = 500, K = 1000: 48 ms + 96 ms of GPU time) are sized for the
+    # GPU's clock management: after an idle period it takes tens of milliseconds of continuous load to
+    # reach its sustained clocks -- on one box W/K = 20/200 gave 96.4 us per launch, 200/500 90.3,
+    # 500/1000 89.7, 2000/4000 88.3 (profiles/r01_bench_warmup_sweep.txt).
     graph = None
     if not args.no_graph:
         try:
@@ -157,6 +161,8 @@ def main():
         except Exception as exc:                      # capture unsupported: fall back to eager launches
             print("bench: graph capture failed (%s), timing eager launches" % exc, file=sys.stderr)
             graph = None
+    for _ in range(args.warmup):
+        eng.stft(pcm, B, N_FFT, HOP, out=spec)
     barrier()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()

@@ -13,7 +13,7 @@ echo "== pytest -m gpu"; timeout -k 10 900 python -m pytest "$R/tests" -m gpu -x
 echo "== smoke"; (cd "$R" && timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke()") 2>&1 | grep smoke | tee "$O/smoke.log"
 echo "== bench"; (cd "$R" && timeout -k 10 300 python bench.py) 2>/dev/null | tail -1 > "$O/bench.json"; cut -c1-300 "$O/bench.json"
 echo "== rocprof bench"
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_bench" -- python3 "$R/bench.py" --steps 200 --warmup 20 --no-cpu-baseline > "$O/prof_bench.log" 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_bench" -- python3 "$R/bench.py" --no-cpu-baseline > "$O/prof_bench.log" 2>&1
 echo "== pmc fetch"
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/pmc_fetch" -- python3 "$R/bench.py" --steps 5 --warmup 2 --no-cpu-baseline > "$O/pmc_fetch.log" 2>&1
 echo "== pmc write"

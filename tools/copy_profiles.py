@@ -18,7 +18,7 @@ P = os.path.join(ROOT, "profiles")
 
 def newest(pat):
     fs = glob.glob(os.path.join(O, pat))
-    fs.sort(key=lambda f: int(os.path.basename(f).split("_")[0]))
+    fs.sort(key=os.path.getmtime)                 # gpurun merges into the local directory: keep the latest run's file
     return fs[-1]
 
 
