@@ -24,9 +24,18 @@ HBM_PEAK = 8000.0       # GB/s
 FP32_PEAK = 157.3       # TFLOP/s vector
 
 
-def timed(fn, iters, rounds=5):
+def timed(fn, iters, rounds=5, spin_ms=60.0):
+    """Median over `rounds` of the mean launch time of `iters` back-to-back calls, after `spin_ms` of the same
+    calls: a GPU that has idled needs tens of milliseconds of load to reach its sustained clocks
+    (profiles/r01_bench_warmup_sweep.txt)."""
+    import time
     fn()
     torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    while (time.perf_counter() - t0) * 1e3 < spin_ms:
+        for _ in range(4):
+            fn()
+        torch.cuda.synchronize()
     ts = []
     for _ in range(rounds):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
