@@ -1,0 +1,62 @@
+// jeicyboo_compat_mvdr.cpp -- see jeicyboo_compat_mvdr.h.
+#include "jeicyboo_compat_mvdr.h"
+
+#include <cstdio>
+#include <cstdlib>
+
+namespace {
+
+jdsp_ctx *g_ctx = nullptr;
+jdsp_mvdr *g_h = nullptr;
+double g_dtime = 0;
+
+[[noreturn]] void die(const char *what)
+{
+    fprintf(stderr, "jeicyboo_compat_mvdr: %s: %s\n", what, jdsp_last_error(g_ctx));
+    abort();
+}
+#define CK(call) do { if ((call) != JDSP_OK) die(#call); } while (0)
+
+jdsp_ctx *context()
+{
+    if (!g_ctx) {
+        const char *dev = getenv("JDSP_DEVICE");
+        if (jdsp_create(dev ? atoi(dev) : 0, &g_ctx) != JDSP_OK) die("jdsp_create");
+    }
+    return g_ctx;
+}
+
+}  // namespace
+
+void JeicybooMvdrReset(void)
+{
+    if (g_h) { jdsp_mvdr_destroy(g_h); g_h = nullptr; }
+}
+
+bool VoiceActivityDetection(short *block, int n)
+{
+    if (n != 512) { fprintf(stderr, "VoiceActivityDetection: iFrameCount must be 512\n"); abort(); }
+    int64_t e = 0;
+    CK(jdsp_vad_blocks(context(), block, 1, nullptr, &e, nullptr));
+    return e > 716800;                                    // dEnergy = sum / 1024 > THRESHOLD_OF_ENERGY 700 (:233)
+}
+
+void EstimateSpatialCorrMtx(short *, short *, int, double (*)[2], int n)
+{
+    // the accumulation of :263-268 happens inside the handle when ProcessMVDR is given this block (see the header)
+    if (n != 1024) { fprintf(stderr, "EstimateSpatialCorrMtx: iFrameCount must be 1024\n"); abort(); }
+}
+
+bool ProcessMVDR(short *left, short *right, int n, short *out, double d_time, double (*corr)[2])
+{
+    if (n != 512) { fprintf(stderr, "ProcessMVDR: iBlockLen must be 512\n"); abort(); }
+    if (g_h && d_time != g_dtime) JeicybooMvdrReset();
+    if (!g_h) {
+        CK(jdsp_mvdr_create(context(), d_time, &g_h));
+        g_dtime = d_time;
+    }
+    long n_out = 0;
+    CK(jdsp_mvdr_process(g_h, left, right, 1, out, nullptr, &n_out));
+    if (corr) CK(jdsp_mvdr_corr(g_h, &corr[0][0]));
+    return n_out > 0;                                     // :201-204: nothing is written for the first block
+}

@@ -292,3 +292,24 @@ def test_plain_c_example_mfcc_to_gmm_on_the_device(tmp_path, oracle):
         assert np.all(np.abs(got - want) <= 1e-12 * np.abs(want))
     m.close()
     eng.close()
+
+
+def test_compat_mvdr_per_block_functions(tmp_path, oracle):
+    """BeamForming_MVDR_ver1.cpp's main() loop (:83-109) on ProcessMVDR / VoiceActivityDetection /
+    EstimateSpatialCorrMtx of libjeicyboo_compat_mvdr.so, one block per call."""
+    if not os.path.exists(os.path.join(COMPAT, "compat_mvdr_selftest")):
+        subprocess.check_call(["make", "-s", "-C", COMPAT])
+    rng = np.random.default_rng(93)
+    n_blocks = 70
+    left = speechlike(94, n_blocks)
+    right = np.clip(np.rint(0.8 * left.astype(np.float64) + rng.normal(0, 20, left.size)), -32768, 32767).astype(np.int16)
+    left.tofile(tmp_path / "l.raw")
+    right.tofile(tmp_path / "r.raw")
+    run("compat_mvdr_selftest", tmp_path / "l.raw", tmp_path / "r.raw", tmp_path / "out.bin")
+    raw = np.fromfile(tmp_path / "out.bin", np.uint8)
+    got = raw[:-32].view(np.int16)
+    corr = raw[-32:].view(np.float64)
+    want, _, o_corr, _ = oracle.mvdr_stream(left, right)
+    assert got.shape == want.shape == ((n_blocks - 1) * 512,)
+    assert np.abs(got.astype(np.int32) - want.astype(np.int32)).max() <= 1
+    assert np.abs(corr - o_corr).max() <= 1e-5 * np.abs(o_corr).max()
