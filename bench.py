@@ -105,6 +105,9 @@ def main():
     ap.add_argument("--no-gather", action="store_true", help="skip the (separately reported) output all_gather at N > 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="time eager launches instead of one hipGraph replay of the K steps")
+    ap.add_argument("--spinup-ms", type=float, default=60.0,
+                    help="untimed load before the W warmup steps so that the GPU is at its sustained clocks whatever W is "
+                         "(0 disables; reported in config.spinup_ms)")
     args = ap.parse_args()
 
     import torch
@@ -161,6 +164,15 @@ def main():
         except Exception as exc:                      # capture unsupported: fall back to eager launches
             print("bench: graph capture failed (%s), timing eager launches" % exc, file=sys.stderr)
             graph = None
+    # Clock spin-up, independent of W: a GPU that has idled needs tens of milliseconds of continuous load to reach
+    # its sustained clocks (profiles/r01_bench_warmup_sweep.txt); a caller that passes a small W would otherwise
+    # time the ramp.  Untimed, like the warmup, and reported in config.spinup_ms.
+    if args.spinup_ms > 0:
+        t_spin = time.perf_counter()
+        while (time.perf_counter() - t_spin) * 1e3 < args.spinup_ms:
+            for _ in range(32):
+                eng.stft(pcm, B, N_FFT, HOP, out=spec)
+            torch.cuda.synchronize()
     for _ in range(args.warmup):
         eng.stft(pcm, B, N_FFT, HOP, out=spec)
     barrier()
@@ -242,7 +254,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": "STFT analysis n_fft=1024 hop=512 Hamming, batch=%d frames/GPU, int16 PCM in HBM -> complex64 full spectrum in HBM" % B,
                        "frames_per_gpu": B, "parallelism": "frame-sharded x%d, no collective" % world,
-                       "launch": "hipGraph replay of the K steps" if graph is not None else "eager"},
+                       "launch": "hipGraph replay of the K steps" if graph is not None else "eager",
+                       "spinup_ms": args.spinup_ms},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": read_traffic(),
                          "kernel": "stft1024_hop512_kernel<2>", "kernel_ms": kern_ms,
