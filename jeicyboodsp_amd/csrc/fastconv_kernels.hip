@@ -588,13 +588,10 @@ int launch_fastconv_upols(hipStream_t st, const ConvStream &s, long n_out_blocks
         const long per_wg = kUpolsWaves * kUpolsK;
         const long grid = ((n_sub + per_wg - 1) / per_wg + 7) / 8 * 8;
         const size_t lds = ((size_t)n_part * kUpolsPitch + kUpolsWaves * (size_t)kWaveLdsComplex) * sizeof(float2);
-        static bool attr_set = false;
-        if (!attr_set) {
-            if (hipFuncSetAttribute((const void *)fastconv_upols4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)((16 * (size_t)kUpolsPitch + kUpolsWaves * (size_t)kWaveLdsComplex) * sizeof(float2))) != hipSuccess)
-                return -1;
-            attr_set = true;
-        }
+        // more than 64 KB of dynamic LDS needs the attribute (per device: set on every launch, it is a host-side flag)
+        if (hipFuncSetAttribute((const void *)fastconv_upols4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)((16 * (size_t)kUpolsPitch + kUpolsWaves * (size_t)kWaveLdsComplex) * sizeof(float2))) != hipSuccess)
+            return -1;
         hipLaunchKernelGGL(fastconv_upols4_kernel, dim3((unsigned)grid), dim3(kUpolsWaves * 64), lds, st, X, Hp, n_part, n_filters,
                            first_row, n_sub, n_frames - 1, rect_table, out, precast, plane);
 #endif
