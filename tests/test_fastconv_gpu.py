@@ -183,3 +183,21 @@ def test_8192_other_tap_counts_and_a_filter_pair(eng, oracle, n_taps, block):
         o_out, o_pre = oracle.fastconv_stream(pcm, taps[f], 8192)
         check(out[f], pre[f], o_out, o_pre, floor=np.abs(pcm).max() * np.abs(taps[f]).sum())
     fc.close()
+
+
+@pytest.mark.parametrize("n_fft,n_taps", [(1024, 200), (8192, 7169), (8192, 7000)])
+def test_three_filters_share_one_forward_transform(eng, oracle, n_fft, n_taps):
+    """More filters than the HRIR pair: every kernel loops its filters over one forward spectrum (the partitioned
+    one reloads the partition spectra into LDS per filter, with workgroup barriers in between)."""
+    rng = np.random.default_rng(n_taps)
+    taps = rng.normal(size=(3, n_taps)) * np.exp(-np.arange(n_taps) / 700.0) * 0.05
+    block = n_fft - n_taps + 1
+    hist = -(-(n_taps - 1) // block)
+    pcm = _pcm(n_taps + 3, (hist + 6) * block)
+    fc = eng.fastconv(taps, n_fft)
+    out, pre = fc.process(pcm, want_precast=True)
+    assert out.shape == (3, 6 * block)
+    for f in range(3):
+        o_out, o_pre = oracle.fastconv_stream(pcm, taps[f], n_fft)
+        check(out[f], pre[f], o_out, o_pre, floor=np.abs(pcm).max() * np.abs(taps[f]).sum())
+    fc.close()
