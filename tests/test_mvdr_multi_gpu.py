@@ -40,7 +40,7 @@ def check(out, pre, o_out, o_pre):
     assert np.abs(out.astype(np.int32) - o_out.astype(np.int32)).max() <= 1
 
 
-@pytest.mark.parametrize("n_mics", [2, 3, 8])
+@pytest.mark.parametrize("n_mics", [2, 3, 5, 7, 8])
 def test_matches_cpu_restatement(eng, oracle, n_mics):
     pcm, _, delays = array_scene(n_mics, n_mics, 50)
     o_out, o_pre = oracle.mvdrn_stream(pcm, delays, 1e-3)
