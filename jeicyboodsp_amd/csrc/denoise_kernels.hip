@@ -110,6 +110,8 @@ __global__ __launch_bounds__(1024) void plan_kernel(const unsigned char *__restr
     __shared__ RunSummary sum[1024];
     __shared__ int cnt_ev[1024], cnt_sn[1024];
     __shared__ int carry_run, carry_ev, carry_sn;
+    __shared__ RunSummary wave_sum[16];
+    __shared__ int wave_ev[16], wave_sn[16];
     const int t = threadIdx.x;
     const int run_len_in = *run_len_in_p;
     if (t == 0) { carry_run = run_len_in; carry_ev = 0; carry_sn = 0; }
@@ -139,12 +141,25 @@ __global__ __launch_bounds__(1024) void plan_kernel(const unsigned char *__restr
         RunSummary mine;
         mine.has_voice = V != 0;
         mine.trailing = V ? (cnt - 1) - (63 - __clzll(V)) : cnt;
-        sum[t] = mine;
-        __syncthreads();
-        for (int o = 1; o < 1024; o <<= 1) {                    // inclusive Hillis-Steele scan
-            RunSummary v = sum[t];
-            if (t >= o) v = combine(sum[t - o], v);
+        // inclusive scan of the run summaries over the 1024 threads: shuffles inside each wave, one pass over the
+        // 16 wave totals, two barriers (a Hillis-Steele scan through LDS took twenty)
+        {
+            const int lane = t & 63, wv = t >> 6;
+            RunSummary v = mine;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                RunSummary u;
+                u.has_voice = __shfl_up(v.has_voice, o, 64);
+                u.trailing = __shfl_up(v.trailing, o, 64);
+                if (lane >= o) v = combine(u, v);
+            }
+            if (lane == 63) wave_sum[wv] = v;
             __syncthreads();
+            if (wv > 0) {
+                RunSummary pre = wave_sum[0];
+                for (int q = 1; q < wv; q++) pre = combine(pre, wave_sum[q]);
+                v = combine(pre, v);
+            }
             sum[t] = v;
             __syncthreads();
         }
@@ -152,23 +167,36 @@ __global__ __launch_bounds__(1024) void plan_kernel(const unsigned char *__restr
         int r = run_in;                                          // run length entering my slice
         if (t > 0) r = sum[t - 1].has_voice ? sum[t - 1].trailing : run_in + sum[t - 1].trailing;
         const int r_start = r;
-        unsigned long long E = 0, S = 0;                         // event / latch masks of my slice
-        for (int i = 0; i < cnt; i++) {
-            if ((V >> i) & 1ull) r = 0;
-            else {
-                r++;
-                if (r >= 2) E |= 1ull << i;
-                if (latch_run > 0 ? r == latch_run : r >= 2) S |= 1ull << i;
+        // event / latch masks of my slice, bit-parallel.  N = noise bits.  An event (run length >= 2) is a noise
+        // bit whose predecessor is noise too -- bit 0's predecessor is the incoming run.  A latch (run length ==
+        // latch_run) is the last of latch_run noise bits that follow a voice bit inside the slice, or bit
+        // latch_run - r_start - 1 when everything up to it is noise (the run came in from before the slice).
+        const unsigned long long full = cnt == 64 ? ~0ull : ((1ull << cnt) - 1ull);
+        const unsigned long long N = ~V & full;
+        const unsigned long long E = N & ((N << 1) | (r_start >= 1 ? 1ull : 0ull));
+        unsigned long long S = E;                                // latch_run == 0: every event changes the estimate
+        if (latch_run > 0) {
+            unsigned long long A = N;
+            for (int k = 1; k < latch_run && k < 64; k++) A &= N << k;
+            S = latch_run < 64 ? (A & (V << latch_run)) : 0ull;
+            const int ic = latch_run - r_start - 1;
+            if (ic >= 0 && ic < cnt) {
+                const unsigned long long upto = (2ull << ic) - 1ull;        // bits 0..ic (all ones for ic = 63)
+                if ((N & upto) == upto) S |= 1ull << ic;
             }
         }
         const int ne = __popcll(E), ns = __popcll(S);
-        cnt_ev[t] = ne;
-        cnt_sn[t] = ns;
-        __syncthreads();
-        for (int o = 1; o < 1024; o <<= 1) {
-            int ve = cnt_ev[t], vs = cnt_sn[t];
-            if (t >= o) { ve += cnt_ev[t - o]; vs += cnt_sn[t - o]; }
+        {
+            const int lane = t & 63, wv = t >> 6;
+            int ve = ne, vs = ns;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int ue = __shfl_up(ve, o, 64), us = __shfl_up(vs, o, 64);
+                if (lane >= o) { ve += ue; vs += us; }
+            }
+            if (lane == 63) { wave_ev[wv] = ve; wave_sn[wv] = vs; }
             __syncthreads();
+            for (int q = 0; q < wv; q++) { ve += wave_ev[q]; vs += wave_sn[q]; }
             cnt_ev[t] = ve;
             cnt_sn[t] = vs;
             __syncthreads();
@@ -179,13 +207,12 @@ __global__ __launch_bounds__(1024) void plan_kernel(const unsigned char *__restr
         }
         if (E) {
             int eo = carry_ev + cnt_ev[t] - ne;
-            r = r_start;
-            for (int i = 0; i < cnt; i++) {
-                if ((V >> i) & 1ull) r = 0;
-                else {
-                    r++;
-                    if (r >= 2) { events[eo] = (int)(a + i); ev_n[eo] = r; eo++; }
-                }
+            for (unsigned long long rest = E; rest; rest &= rest - 1ull) {
+                const int i = __ffsll((long long)rest) - 1;
+                const unsigned long long below = V & ((1ull << i) - 1ull);    // voice bits before i (bit i is noise)
+                events[eo] = (int)(a + i);
+                ev_n[eo] = below ? i - (63 - __clzll((long long)below)) : r_start + i + 1;
+                eo++;
             }
         }
         __syncthreads();
