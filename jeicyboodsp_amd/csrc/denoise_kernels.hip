@@ -55,13 +55,17 @@ __global__ __launch_bounds__(64) void vad_kernel(const short *__restrict__ pcm, 
         x[6] = (short)(img[i].w & 0xffffu); x[7] = (int)img[i].w >> 16;
         x[8] = __shfl_down(x[0], 1);                   // first sample of the next lane
         if (lane == 63) x[8] = 0;                      // block sample 512 does not exist: frame[1024], defined 0
+        // s and x are 16-bit quantities: 24-bit multiplies (full rate; the 32-bit v_mul_lo is quarter rate) are
+        // exact, and four squares (< 2^30 each) fit an unsigned 32-bit partial sum
         long long e = 0;
+        unsigned int q4 = 0;
         int z = 0;
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             const int s = (int)((double)x[k] * w[k]);  // (short)(short * double), in range
-            e += (long long)s * s;
-            z += (s * x[k + 1] < 0) ? 1 : 0;
+            q4 += (unsigned int)__mul24(s, s);
+            if ((k & 3) == 3) { e += (long long)q4; q4 = 0; }
+            z += (__mul24(s, x[k + 1]) < 0) ? 1 : 0;
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
