@@ -132,9 +132,12 @@ __global__ __launch_bounds__(64) void mvdr_kernel(const short *__restrict__ left
                                                   const float2 *__restrict__ table, short *__restrict__ out,
                                                   float *__restrict__ precast, DenoiseShard sh)
 {
-    __shared__ __attribute__((aligned(16))) float2 lds[kWaveLdsComplex];
-    __shared__ __attribute__((aligned(16))) float2 merged[1024];
-    __shared__ __attribute__((aligned(16))) unsigned int stage32[520];
+    // One 8 KB buffer, used in turn as: transform scratch (first 584 elements) with the frame-assembly stage in
+    // its tail, the merged 1024-bin spectrum, and the scratch of the inverse transform.  (Three separate arrays
+    // were 15 KB per wave and capped the CU at 10 waves.)
+    __shared__ __attribute__((aligned(16))) float2 buf[1024];
+    float2 *lds = buf, *merged = buf;
+    unsigned int *stage32 = reinterpret_cast<unsigned int *>(buf + 600);      // 520 dwords of the 848 after element 600
     const int lane = threadIdx.x;
     const long per_xcd = (gridDim.x + 7) >> 3;
     const long j = (long)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
@@ -154,6 +157,7 @@ __global__ __launch_bounds__(64) void mvdr_kernel(const short *__restrict__ left
                      mvdr_load_block(right, n_blocks, st_in->prev_r, j, lane), v, 0.5f);
     spectrum_of(v, lds, lane, tw, wsp, rlo, rhi);
 
+    wave_lds_fence();                      // the split reads of the second spectrum are done: `merged` may overwrite
     // mxAutoCorr.inverse() (:170) for the matrix in effect at this block
     int ver = version_of(ver_base, snap_mask, j + sh.ver_block_off);
     if (sh.ver_row_off) ver -= *sh.ver_row_off;
@@ -204,6 +208,7 @@ __global__ __launch_bounds__(64) void mvdr_kernel(const short *__restrict__ left
     }
     JDSP_HERM(0) JDSP_HERM(1) JDSP_HERM(2) JDSP_HERM(3)
 #undef JDSP_HERM
+    wave_lds_fence();                      // every lane has read `merged`: the same memory becomes the inverse's scratch
 #pragma unroll
     for (int q = 0; q < 4; q++)
         *reinterpret_cast<float4 *>(&lds[128 * q + 2 * lane]) = make_float4(z[2 * q].x, z[2 * q].y, z[2 * q + 1].x, z[2 * q + 1].y);
