@@ -352,15 +352,24 @@ __global__ __launch_bounds__(256) void noise_scan_kernel(const float *__restrict
 // ---------------------------------------------------------------------------------------
 // A8 (SS:233-242): Y = (|X| - N) e^{j phase(X)}; no clamp at zero; X == 0 -> phase 0 -> (-N, 0).
 // A9 (WF:196-213): Y = |X| (1 - min(1, N^2/|X|^2)) e^{j phase(X)}; 0/0 stays NaN as in the reference.
+#ifndef JDSP_GAIN_SELECT
+#define JDSP_GAIN_SELECT 1
+#endif
 template <int MODE>
 __device__ __forceinline__ float2 apply_gain(float2 x, float n)
 {
     // hardware reciprocal / reciprocal square root (1 ulp): the bar is 1e-5, not IEEE division
     const float p = x.x * x.x + x.y * x.y;
     if (MODE == 0) {
+#if JDSP_GAIN_SELECT
+        const float g = 1.0f - n * __frsqrt_rn(p);           // (|X| - N) / |X|; p == 0 gives inf / NaN, replaced below
+        const bool zero = p == 0.0f;
+        return make_float2(zero ? -n : x.x * g, zero ? 0.0f : x.y * g);
+#else
         if (p == 0.0f) return make_float2(-n, 0.0f);
         const float g = 1.0f - n * __frsqrt_rn(p);           // (|X| - N) / |X|
         return make_float2(x.x * g, x.y * g);
+#endif
     } else {
         float r = (n * n) * __frcp_rn(p);                    // 0 * inf = NaN keeps the reference's 0/0
         if (r >= 1.0f) r = 1.0f;
