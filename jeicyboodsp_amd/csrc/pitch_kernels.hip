@@ -80,14 +80,21 @@ __global__ __launch_bounds__(64) void pitch_autocorr_kernel(const short *__restr
         const float a = y[d].x * (1.0f / 1024.0f), c = y[d].y * (1.0f / 1024.0f);
         if (autocorr) *reinterpret_cast<float2 *>(autocorr + b * 512 + i0) = make_float2(a, c);
         // :102-108 scans 511 -> 101 with >=: the largest value wins, ties go to the SMALLEST lag
-        if (i0 > 100 && (a > best || (a == best && i0 < at))) { best = a; at = i0; }
-        if (i0 + 1 > 100 && (c > best || (c == best && i0 + 1 < at))) { best = c; at = i0 + 1; }
+        // (bitwise, not short-circuit, conditions: selects instead of divergent branches)
+        const bool ta = (i0 > 100) & ((a > best) | ((a == best) & (i0 < at)));
+        best = ta ? a : best;
+        at = ta ? i0 : at;
+        const bool tc = (i0 + 1 > 100) & ((c > best) | ((c == best) & (i0 + 1 < at)));
+        best = tc ? c : best;
+        at = tc ? i0 + 1 : at;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         const float ob = __shfl_xor(best, o);
         const int oa = __shfl_xor(at, o);
-        if (ob > best || (ob == best && oa < at)) { best = ob; at = oa; }
+        const bool to = (ob > best) | ((ob == best) & (oa < at));
+        best = to ? ob : best;
+        at = to ? oa : at;
     }
     if (lane == 0) {
         arg[b] = at;
