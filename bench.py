@@ -6,17 +6,28 @@ at batch = 65,536 frames per GPU (BASELINE.json `metric`).
 
 A "step" is one pass of the hot path (jdsp_stft_i16_dev: int16 framing + window
 + forward transform, full 1024-bin complex64 spectrum) over one batch of
-synthetic PCM that is already resident in HBM.  For N > 1 the driver launches
-one rank per GPU with torch.distributed.run; frames are independent, so every
-rank transforms its own shard of N*65,536 frames (weak scaling, no data-path
-collective); `--gather` additionally times an RCCL all_gather of the spectra and
-reports it separately (never part of `value`).
+synthetic PCM that is already resident in HBM.  Successive steps read DIFFERENT
+PCM buffers (--pcm-buffers, default 6 x 64 MiB = 384 MiB > the 256 MiB Infinity
+Cache), so the input of every timed launch comes from HBM, not from a cache that
+the previous launch warmed; the same-buffer figure is reported beside it
+(`roofline.warm_input`).
+
+N > 1: one rank per GPU over RCCL.  Either an external launcher started the ranks
+(`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`: RANK
+is set) or this script starts them itself: `python bench.py --gpus N` spawns
+`torch.distributed.run` as a CHILD process before anything touches the GPU,
+relays rank 0's JSON line and exits with the children's status.  Frames are
+independent, so every rank transforms its own shard of N*65,536 frames (weak
+scaling, no data-path collective); the output all_gather is timed separately and
+never part of `value`.
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -26,8 +37,55 @@ sys.path.insert(0, ROOT)
 N_FFT, HOP, FRAMES_PER_GPU = 1024, 512, 65536
 BYTES_PER_FRAME = 512 * 2 + 1024 * 8          # 9,216 B algorithmic
 HBM_PEAK_GBS = 8000.0                         # MI355X_MICROARCH.md: 8.0 TB/s spec
+TRAFFIC_FILE = os.path.join("profiles", "stft_pmc_traffic.json")
+EXIT_STUCK_COLLECTIVE = 3
 
 
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=500)
+    ap.add_argument("--frames", type=int, default=FRAMES_PER_GPU, help="frames per GPU per step")
+    ap.add_argument("--pcm-buffers", type=int, default=6,
+                    help="distinct PCM input buffers the steps rotate over (1 = every step re-reads the same buffer)")
+    ap.add_argument("--gather", action="store_true", help="time the all_gather of the spectra even with one rank")
+    ap.add_argument("--no-gather", action="store_true", help="skip the (separately reported) output all_gather at N > 1")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="time eager launches instead of one hipGraph replay of the K steps")
+    ap.add_argument("--spinup-ms", type=float, default=60.0,
+                    help="untimed load before the W warmup steps so that the GPU is at its sustained clocks whatever W is "
+                         "(0 disables; reported in config.spinup_ms)")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="torch.distributed backend: nccl (= RCCL over xGMI, the product path) or gloo (host-staged "
+                         "gather; for rehearsing N ranks on a box with fewer GPUs -- ranks then share GPUs)")
+    ap.add_argument("--launcher-selftest", action="store_true",
+                    help="no GPU work at all: ranks rendezvous, barrier, reduce the timings and gather a dummy buffer, "
+                         "so the N > 1 launch path can be tested on a CPU-only host (the line says so; value is null)")
+    return ap.parse_args(argv)
+
+
+# ------------------------------------------------------------------ N > 1: start the ranks ourselves
+def rank_command(args, argv, port):
+    """The child command for `python bench.py --gpus N` (N > 1, no RANK in the environment)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def launch_ranks(args, argv):
+    """Parent of an N-rank run.  Never imports torch / touches HIP itself (a process that has
+    initialised the GPU must not spawn the job that uses it by exec; this one spawns a child and
+    waits).  stdout/stderr are inherited, so rank 0's JSON line is this process's JSON line."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this pool (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.run(rank_command(args, argv, port), env=env, stdin=subprocess.DEVNULL).returncode
+
+
+# ------------------------------------------------------------------ inputs, baselines
 def synth_pcm(rank, n_frames, world=1):
     """SURVEY.md §8d synthetic input: normal(0, 3000) rounded and clipped to int16, (B+1)*512 samples
     per rank = B frames + the 512-sample halo (jeicyboodsp_amd.sharding.stft_shard).  Rank 0 draws
@@ -39,6 +97,23 @@ def synth_pcm(rank, n_frames, world=1):
     assert s.count == n_frames and s.sample_count == HOP * (n_frames - 1) + N_FFT
     rng = np.random.default_rng(rank)
     return np.clip(np.rint(rng.normal(0.0, 3000.0, s.sample_count)), -32768, 32767).astype(np.int16)
+
+
+def host_cpu_share():
+    """(cores visible to this process, cgroup CPU quota in cores or None)."""
+    try:
+        visible = len(os.sched_getaffinity(0))
+    except AttributeError:
+        visible = os.cpu_count() or 1
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, period = f.read().split()
+        if q != "max":
+            quota = float(q) / float(period)
+    except Exception:
+        pass
+    return visible, quota
 
 
 def cpu_baseline(seconds=10.0):
@@ -59,21 +134,21 @@ def cpu_baseline(seconds=10.0):
         if dt >= seconds:
             break
     one = done / dt
-    # several host cores: frames are independent, static partition over threads (ctypes drops the
-    # GIL).  Capped at this job's CPU share of the GPU box (16 threads for one GPU).
+    # every host core this job may use: frames are independent, static partition over threads (ctypes
+    # drops the GIL).  Threads = the cores visible to the process (nproc), cut to the cgroup's CPU quota
+    # when there is one (more runnable threads than the quota only adds contention) -- both are reported.
     import threading
-    try:
-        avail = len(os.sched_getaffinity(0))
-    except AttributeError:
-        avail = os.cpu_count() or 1
-    cores = max(1, min(16, avail))
+    visible, quota = host_cpu_share()
+    cores = max(1, min(visible, int(quota) if quota and quota >= 1 else visible))
+    small = 512                                    # shorter calls so that 256 threads all finish inside the window
+    pcm_s = pcm[: 512 * (small + 1)]
     counts = [0] * cores
     stop = time.perf_counter() + min(seconds, 8.0)
 
     def work(i):
         while time.perf_counter() < stop:
-            orc.stft(pcm, chunk)
-            counts[i] += chunk
+            orc.stft(pcm_s, small)
+            counts[i] += small
 
     t0 = time.perf_counter()
     th = [threading.Thread(target=work, args=(i,)) for i in range(cores)]
@@ -82,57 +157,117 @@ def cpu_baseline(seconds=10.0):
     allc = sum(counts) / (time.perf_counter() - t0)
     return {"value": one, "unit": "frames/s", "cores": 1, "kind": "port",
             "sample": "%d frames (chunks of %d from the same synthetic stream), FP64 oracle, single thread" % (done, chunk),
-            "multi_thread": {"value": allc, "cores": cores, "host_cores_visible": avail}}
+            "all_cores": {"value": allc, "unit": "frames/s", "threads": cores, "nproc": visible,
+                          "cgroup_cpu_quota": quota,
+                          "note": "same oracle, one thread per usable host core (nproc cut to the cgroup CPU quota if any)"}}
 
 
 def read_traffic():
-    """HBM bytes per launch from the committed PMC pass (profiles/r01_stft_pmc.json), or None."""
-    p = os.path.join(ROOT, "profiles", "stft_pmc_traffic.json")
+    """HBM bytes per launch from the committed PMC pass (a constant of that collection, NOT measured by
+    this run: rocprofv3 --pmc needs its own passes), or None."""
     try:
-        with open(p) as f:
+        with open(os.path.join(ROOT, TRAFFIC_FILE)) as f:
             return json.load(f).get("hbm_bytes_per_launch")
     except Exception:
         return None
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1000)
-    ap.add_argument("--warmup", type=int, default=500)
-    ap.add_argument("--frames", type=int, default=FRAMES_PER_GPU, help="frames per GPU per step")
-    ap.add_argument("--gather", action="store_true", help="time the RCCL all_gather of the spectra even with one rank")
-    ap.add_argument("--no-gather", action="store_true", help="skip the (separately reported) output all_gather at N > 1")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-graph", action="store_true", help="time eager launches instead of one hipGraph replay of the K steps")
-    ap.add_argument("--spinup-ms", type=float, default=60.0,
-                    help="untimed load before the W warmup steps so that the GPU is at its sustained clocks whatever W is "
-                         "(0 disables; reported in config.spinup_ms)")
-    args = ap.parse_args()
-
-    import torch
-    import jeicyboodsp_amd
-
+# ------------------------------------------------------------------ one rank
+def init_dist(args):
+    """(dist module or None, rank, world, local_rank)"""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    if world > 1 or "RANK" in os.environ:            # launched by torch.distributed.run: one rank per GPU, RCCL
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29500")
-        os.environ.setdefault("RANK", "0")
-        os.environ.setdefault("WORLD_SIZE", "1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if world == 1 and "RANK" not in os.environ:
+        return None, 0, 1, 0
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29500")
+    os.environ.setdefault("RANK", "0")
+    os.environ.setdefault("WORLD_SIZE", "1")
+    if args.backend == "nccl" and not args.launcher_selftest:
+        n_dev = max(torch.cuda.device_count(), 1)
+        torch.cuda.set_device(local_rank % n_dev)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank % n_dev))
     else:
-        torch.cuda.set_device(0)
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
-    dev = torch.device("cuda", local_rank)
+        dist.init_process_group("gloo")
+    return dist, rank, world, local_rank
 
-    eng = jeicyboodsp_amd.Engine(local_rank)
+
+def guarded(work_launch, deadline_s, sync=None):
+    """Launches an async collective and polls it against a deadline: False = still pending."""
+    work = work_launch()
+    t_end = time.perf_counter() + deadline_s
+    while not work.is_completed():
+        if time.perf_counter() > t_end:
+            return False
+        time.sleep(0.0005)
+    if sync:
+        sync()
+    return True
+
+
+def selftest_rank(args):
+    """--launcher-selftest: everything of an N-rank run except the GPU (rendezvous, barriers, MAX
+    reduction of the timings, the output gather on a dummy buffer, the JSON line, the shutdown)."""
+    import torch
+    dist, rank, world, _ = init_dist(args)
+    assert world == args.gpus, "world size %d != --gpus %d" % (world, args.gpus)
     B = args.frames
-    pcm = torch.from_numpy(synth_pcm(rank, B, world)[: 512 * (B + 1)].copy()).to(dev)
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pass
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64)
+    gather_ms = None
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        flat = torch.full((B, N_FFT, 2), float(rank), dtype=torch.float32)
+        out = torch.empty((world * B,) + tuple(flat.shape[1:]), dtype=flat.dtype)     # concatenated along dim 0
+        t1 = time.perf_counter()
+        dist.all_gather_into_tensor(out, flat)
+        gather_ms = (time.perf_counter() - t1) * 1e3
+        assert all(float(out[r * B, 0, 0]) == float(r) for r in range(world))
+    if rank == 0:
+        print(json.dumps({"metric": "launcher self-test (no GPU work, not a measurement)", "value": None,
+                          "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": float(t[0]) / max(args.steps, 1) * 1e3, "higher_is_better": True,
+                          "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "none",
+                          "config": {"workload": "launcher self-test", "backend": "gloo", "frames_per_gpu": B},
+                          "gather": {"ms": gather_ms, "bytes_per_rank": B * N_FFT * 8}}), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
+def run_rank(args):
+    import torch
+    import jeicyboodsp_amd
+
+    dist, rank, world, local_rank = init_dist(args)
+    assert world == args.gpus, "world size %d != --gpus %d (start the ranks with torch.distributed.run, or let " \
+                               "`python bench.py --gpus N` start them)" % (world, args.gpus)
+    n_dev = torch.cuda.device_count()
+    assert n_dev >= 1, "bench.py needs a GPU (no CPU fallback)"
+    if args.backend == "nccl":
+        assert world <= n_dev, "nccl: %d ranks need %d GPUs, %d visible (rehearse with --backend gloo)" % (world, world, n_dev)
+    dev_index = local_rank % n_dev
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+
+    eng = jeicyboodsp_amd.Engine(dev_index)
+    B = args.frames
+    P = max(1, args.pcm_buffers)
+    base = torch.from_numpy(synth_pcm(rank, B, world)[: 512 * (B + 1)].copy()).to(dev)
+    # P distinct buffers (distinct addresses are what defeats the cache; the content is the same noise rotated
+    # by a whole number of frames, so every buffer is the SURVEY §8d stream: no all-zero frames)
+    pcms = [base] + [torch.roll(base, 512 * 97 * i).contiguous() for i in range(1, P)]
     spec = torch.empty((B, N_FFT), dtype=torch.complex64, device=dev)
 
     def barrier():
@@ -140,97 +275,120 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    eng.stft(pcm, B, N_FFT, HOP, out=spec)            # builds the handle's constant tables (first call only)
+    def step(i, bufs):
+        eng.stft(bufs[i % len(bufs)], B, N_FFT, HOP, out=spec)
+
+    step(0, pcms)                                     # builds the handle's constant tables (first call only)
     barrier()
+
     # Timed region: EXACTLY K launches, captured once into a hipGraph (jdsp_stft_i16_dev only
     # enqueues: no allocation, no sync) and replayed, so the host's per-launch overhead is not in
     # the way; bracketed by HIP events on the launch stream and by barriers for the wall clock.
     # The capture comes BEFORE the warmup, so that the W warmup launches run right up to the barrier that
     # opens the timed region.  The defaults (W = 500, K = 1000: 48 ms + 96 ms of GPU time) are sized for the
     # GPU's clock management: after an idle period it takes tens of milliseconds of continuous load to
-    # reach its sustained clocks -- on one box W/K = 20/200 gave 96.4 us per launch, 200/500 90.3,
-    # 500/1000 89.7, 2000/4000 88.3 (profiles/r01_bench_warmup_sweep.txt).
-    graph = None
-    if not args.no_graph:
+    # reach its sustained clocks (profiles/r01_bench_warmup_sweep.txt).
+    def capture(bufs):
+        if args.no_graph:
+            return None
         try:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
-            graph = torch.cuda.CUDAGraph()
+            g = torch.cuda.CUDAGraph()
             with torch.cuda.stream(side):
-                with torch.cuda.graph(graph, stream=side):
-                    for _ in range(args.steps):
-                        eng.stft(pcm, B, N_FFT, HOP, out=spec)
+                with torch.cuda.graph(g, stream=side):
+                    for i in range(args.steps):
+                        step(i, bufs)
             torch.cuda.current_stream().wait_stream(side)
+            return g
         except Exception as exc:                      # capture unsupported: fall back to eager launches
             print("bench: graph capture failed (%s), timing eager launches" % exc, file=sys.stderr)
-            graph = None
+            return None
+
+    def timed(bufs, graph):
+        for i in range(args.warmup):
+            step(i, bufs)
+        barrier()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record()
+        if graph is not None:
+            graph.replay()
+        else:
+            for i in range(args.steps):
+                step(i, bufs)
+        e1.record()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        return elapsed, e0.elapsed_time(e1) / max(args.steps, 1)   # wall clock; average launch duration (incl. gaps)
+
+    graph = capture(pcms)
+    graph_warm = capture(pcms[:1]) if P > 1 else None
     # Clock spin-up, independent of W: a GPU that has idled needs tens of milliseconds of continuous load to reach
-    # its sustained clocks (profiles/r01_bench_warmup_sweep.txt); a caller that passes a small W would otherwise
-    # time the ramp.  Untimed, like the warmup, and reported in config.spinup_ms.
+    # its sustained clocks; a caller that passes a small W would otherwise time the ramp.  Untimed, like the warmup,
+    # and reported in config.spinup_ms.
     if args.spinup_ms > 0:
         t_spin = time.perf_counter()
+        i = 0
         while (time.perf_counter() - t_spin) * 1e3 < args.spinup_ms:
             for _ in range(32):
-                eng.stft(pcm, B, N_FFT, HOP, out=spec)
+                step(i, pcms)
+                i += 1
             torch.cuda.synchronize()
-    for _ in range(args.warmup):
-        eng.stft(pcm, B, N_FFT, HOP, out=spec)
-    barrier()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    e0.record()
-    if graph is not None:
-        graph.replay()
-    else:
-        for _ in range(args.steps):
-            eng.stft(pcm, B, N_FFT, HOP, out=spec)
-    e1.record()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    kern_ms = e0.elapsed_time(e1) / max(args.steps, 1)      # average launch duration (incl. launch gaps)
+    warm = None
+    if P > 1:                                         # secondary figure first: every step re-reads ONE buffer
+        warm = timed(pcms[:1], graph_warm)
+    elapsed, kern_ms = timed(pcms, graph)             # the reported figure: input rotated over P buffers
 
-    # whole-job timing first: MAX over ranks of the wall clock and of the per-launch duration
-    t = torch.tensor([elapsed, kern_ms], dtype=torch.float64, device=dev)
+    # whole-job timing: MAX over ranks of the wall clock and of the per-launch duration
+    t = torch.tensor([elapsed, kern_ms] + (list(warm) if warm else [0.0, 0.0]), dtype=torch.float64, device=dev)
     if dist is not None:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed, kern_ms = float(t[0]), float(t[1])
+        tt = t.cpu() if args.backend == "gloo" else t
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        t = tt
+    elapsed, kern_ms, warm_elapsed, warm_kern_ms = (float(x) for x in t)
 
     # The only collective of the path: gathering the spectra (RCCL all_gather over xGMI).  Timed
     # AFTER and OUTSIDE the timed region, reported separately, never part of `value` (SURVEY §8e asks for
     # both figures at N > 1: at 8 GPUs the gather costs far more than the transform).  On by default when
     # there is more than one rank.  Every collective of this phase is launched asynchronously and polled
-    # against a deadline, so that a stuck gather costs the gather figure, never the bench line.
+    # against a deadline, so that a stuck gather costs the gather figure, never the bench line -- and the
+    # process then exits non-zero.
     gather_ms = None
     stuck = False
-
-    def guarded(launch, deadline_s):
-        work = launch()
-        t_end = time.perf_counter() + deadline_s
-        while not work.is_completed():
-            if time.perf_counter() > t_end:
-                return False
-            time.sleep(0.0005)
-        torch.cuda.synchronize()
-        return True
-
+    gather_note = None
     if dist is not None and (args.gather or (world > 1 and not args.no_gather)):
         try:
             flat = torch.view_as_real(spec)
-            gathered = torch.empty((world,) + tuple(flat.shape), dtype=flat.dtype, device=dev)
-            launch = lambda: dist.all_gather_into_tensor(gathered, flat, async_op=True)   # noqa: E731
-            stuck = not guarded(launch, 120.0)
+            if args.backend == "gloo":                # gloo has no device all_gather: stage through the host
+                src = flat.cpu()
+                gathered = torch.empty((world * B,) + tuple(src.shape[1:]), dtype=src.dtype)
+                sync = None
+                gather_note = "gloo, host-staged (rehearsal transport, not xGMI)"
+            else:
+                src = flat
+                gathered = torch.empty((world * B,) + tuple(flat.shape[1:]), dtype=flat.dtype, device=dev)
+                sync = torch.cuda.synchronize
+                gather_note = "RCCL all_gather_into_tensor"
+            launch = lambda: dist.all_gather_into_tensor(gathered, src, async_op=True)   # noqa: E731
+            stuck = not guarded(launch, 120.0, sync)
             if not stuck:
                 t1 = time.perf_counter()
                 for _ in range(3):
-                    stuck = stuck or not guarded(launch, 60.0)
+                    stuck = stuck or not guarded(launch, 60.0, sync)
                 local_ms = (time.perf_counter() - t1) / 3 * 1e3
             if not stuck:
-                g = torch.tensor([local_ms], dtype=torch.float64, device=dev)
-                stuck = not guarded(lambda: dist.all_reduce(g, op=dist.ReduceOp.MAX, async_op=True), 60.0)
+                g = torch.tensor([local_ms], dtype=torch.float64, device=None if args.backend == "gloo" else dev)
+                stuck = not guarded(lambda: dist.all_reduce(g, op=dist.ReduceOp.MAX, async_op=True), 60.0, sync)
                 if not stuck:
                     gather_ms = float(g[0])
+                    # the gathered buffer really holds every rank's spectra: rank r's first bin of frame 0
+                    mine = gathered[rank * B, 0].to("cpu")
+                    assert torch.equal(mine, flat[0, 0].to("cpu")), "gathered shard differs from the local spectra"
             if stuck:
-                print("bench: output gather did not complete in time, reported as null", file=sys.stderr)
+                print("bench: output gather did not complete in time", file=sys.stderr)
+        except AssertionError:
+            raise
         except Exception as exc:
             print("bench: output gather skipped (%s)" % exc, file=sys.stderr)
             gather_ms = None
@@ -238,7 +396,8 @@ def main():
     if rank == 0:
         frames_total = float(B) * world * args.steps
         value = frames_total / elapsed
-        ach = BYTES_PER_FRAME * B / (kern_ms * 1e-3) / 1e9
+        alg = BYTES_PER_FRAME * B
+        ach = alg / (kern_ms * 1e-3) / 1e9
         line = {
             "metric": "STFT frames/s (1024-pt, 50% OLA)",
             "value": value,
@@ -255,29 +414,56 @@ def main():
             "config": {"workload": "STFT analysis n_fft=1024 hop=512 Hamming, batch=%d frames/GPU, int16 PCM in HBM -> complex64 full spectrum in HBM" % B,
                        "frames_per_gpu": B, "parallelism": "frame-sharded x%d, no collective" % world,
                        "launch": "hipGraph replay of the K steps" if graph is not None else "eager",
-                       "spinup_ms": args.spinup_ms},
+                       "spinup_ms": args.spinup_ms,
+                       "pcm_buffers": P, "pcm_bytes_total": P * int(base.numel()) * 2,
+                       "input": ("step i reads PCM buffer i %% %d (%d MiB in all, larger than the 256 MiB Infinity Cache): cold input"
+                                 % (P, P * int(base.numel()) * 2 >> 20)) if P > 1 else "every step re-reads the same PCM buffer",
+                       "backend": args.backend if dist is not None else None},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": read_traffic(),
+                         "traffic_source": TRAFFIC_FILE + " (committed rocprofv3 --pmc passes of this command; a constant of "
+                                           "that collection, not measured by the run that printed this line)",
                          "kernel": "stft1024_hop512_kernel<2>", "kernel_ms": kern_ms,
-                         "algorithmic_bytes_per_launch": BYTES_PER_FRAME * B},
+                         "algorithmic_bytes_per_launch": alg},
         }
+        if warm is not None:
+            w_ach = alg / (warm_kern_ms * 1e-3) / 1e9
+            line["roofline"]["warm_input"] = {"kernel_ms": warm_kern_ms, "achieved": w_ach, "frac": w_ach / HBM_PEAK_GBS,
+                                              "value": frames_total / warm_elapsed,
+                                              "note": "same K steps with every step re-reading ONE 64 MiB PCM buffer (cache-resident input)"}
         if gather_ms is not None:
-            line["gather"] = {"ms": gather_ms, "bytes_per_rank": B * N_FFT * 8,
+            line["gather"] = {"ms": gather_ms, "bytes_per_rank": B * N_FFT * 8, "transport": gather_note,
                               "frames_per_s_including_gather": float(B) * world / (elapsed / args.steps + gather_ms * 1e-3)}
+        elif stuck:
+            line["gather"] = {"stuck": True}
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)
 
     eng.close()
-    if stuck:                                         # a collective is still pending: do not wait on it
+    if stuck:                                         # a collective is still pending: do not wait on it, and say so
         sys.stdout.flush()
-        os._exit(0)
+        sys.stderr.flush()
+        os._exit(EXIT_STUCK_COLLECTIVE)
     if dist is not None:
         if not guarded(lambda: dist.barrier(async_op=True), 60.0):
             sys.stdout.flush()
-            os._exit(0)
+            sys.stderr.flush()
+            os._exit(EXIT_STUCK_COLLECTIVE)
         dist.destroy_process_group()
+    return 0
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # BEFORE importing torch or touching the GPU: this process only starts the ranks and waits for them
+        return launch_ranks(args, argv)
+    if args.launcher_selftest:
+        return selftest_rank(args)
+    return run_rank(args)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

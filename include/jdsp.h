@@ -60,7 +60,12 @@ int jdsp_destroy(jdsp_ctx *ctx);
 const char *jdsp_last_error(const jdsp_ctx *ctx);   /* ctx may be NULL: global creation error */
 /* Enqueue on a caller-owned hipStream_t (e.g. the caller framework's current
  * stream).  The value is used as given: NULL is HIP's default (null) stream.
- * jdsp_use_own_stream() goes back to the handle's private non-blocking stream. */
+ * jdsp_use_own_stream() goes back to the handle's private non-blocking stream.
+ * When the stream actually changes, everything the handle (and its stream objects:
+ * create/reset memsets, state carried between process calls) has enqueued on the
+ * old stream is ordered before what follows on the new one (event record + wait;
+ * no host synchronisation).  Exception: if either stream is being captured into a
+ * hipGraph no event is inserted and that ordering is the caller's. */
 int jdsp_set_stream(jdsp_ctx *ctx, void *hip_stream);
 int jdsp_use_own_stream(jdsp_ctx *ctx);
 /* Tuning knobs, by name; unknown names return JDSP_EINVAL.
@@ -96,6 +101,17 @@ int jdsp_fft_process_f64(jdsp_ctx *ctx, const double *in_host, double *out_host,
                          int n_fft, long batch, int forward);
 int jdsp_fft_process_f64_dev(jdsp_ctx *ctx, const double *in_dev, double *out_dev,
                              int n_fft, long batch, int forward);
+
+/* DFTProcess (FFTAlgorithm_ver2.cpp:162-173), IDFTProcess (:175-184) and IFFTProcess (:151-160): the
+ * reference's definition-level O(N^2) transforms, evaluated on the device as the reference writes them
+ * (angle ((2*PI)*i)*k/N with its PI 3.14159265358, terms added in i order, nothing fused) and, like the
+ * reference, ACCUMULATED into the output the caller passes in (a caller that wants the plain transform
+ * zeroes it first, as the reference's commented-out call sites :74,:76 would have to).  Any n >= 1 --
+ * these are not restricted to powers of two.  `batch` independent transforms of length n, back to back.
+ * in: int16[n] per transform for JDSP_DFT_I16, interleaved double (COMPLEX) otherwise. */
+enum { JDSP_DFT_I16 = 0, JDSP_IDFT = 1, JDSP_IDFT_OVER_N = 2 };
+int jdsp_dft_direct_f64_dev(jdsp_ctx *ctx, int kind, const void *in_dev, double *inout_dev, int n, long batch);
+int jdsp_dft_direct_f64(jdsp_ctx *ctx, int kind, const void *in_host, double *inout_host, int n, long batch);
 
 /* ---- STFT analysis: framing + Hamming + forward transform -------------------- */
 /* Replaces, for n_frames frames at once, SpectralSubtraction_final.cpp:218-230

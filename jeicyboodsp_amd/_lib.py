@@ -59,6 +59,8 @@ def _load():
         "jdsp_bitrev_table": (i, [vp, i, i, vp]),
         "jdsp_fft_process_f64": (i, [vp, vp, vp, i, l, i]),
         "jdsp_fft_process_f64_dev": (i, [vp, vp, vp, i, l, i]),
+        "jdsp_dft_direct_f64": (i, [vp, i, vp, vp, i, l]),
+        "jdsp_dft_direct_f64_dev": (i, [vp, i, vp, vp, i, l]),
         "jdsp_denoise_create": (i, [vp, i, C.POINTER(vp)]),
         "jdsp_denoise_destroy": (i, [vp]),
         "jdsp_denoise_reset": (i, [vp]),

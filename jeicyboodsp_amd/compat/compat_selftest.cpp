@@ -1,6 +1,6 @@
 // compat_selftest.cpp -- drives the reference-signature functions exactly the way the
 // reference main()s do (one block per call) and dumps what they return, for tests/ to compare
-// with the CPU checker.  usage: compat_selftest <ss|wf|conv|mfcc|pitch|awgn|fft|gmm|hmm> in.raw out.bin [taps.f64 | params.bin]
+// with the CPU checker.  usage: compat_selftest <ss|wf|conv|mfcc|pitch|awgn|fft|dft|gmm|hmm> in.raw out.bin [taps.f64 | params.bin]
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -97,6 +97,23 @@ int main(int argc, char **argv)
             fwrite(&s, 8, 1, out);
         }
         fclose(fp);
+    } else if (!strcmp(what, "dft")) {
+        // DFTProcess / IDFTProcess / IFFTProcess (FFTAlgorithm_ver2.cpp:151-184) the way the commented-out
+        // call sites (:74,:76) use them, n = argv[4] (default 512; any n, not only powers of two).  The output
+        // arrays are PRE-FILLED with (k, -2k) instead of zeros: the reference accumulates into them.
+        const int n = argc > 4 ? atoi(argv[4]) : 512;
+        std::vector<COMPLEX> spec(n), acc(n);
+        for (size_t blk = 0; blk + n <= pcm.size(); blk += n) {
+            for (int k = 0; k < n; k++) { spec[k].real = k; spec[k].imag = -2.0 * k; }
+            DFTProcess(&pcm[blk], spec.data(), n);
+            fwrite(spec.data(), sizeof(COMPLEX), n, out);
+            for (int k = 0; k < n; k++) { acc[k].real = k; acc[k].imag = -2.0 * k; }
+            IDFTProcess(spec.data(), acc.data(), n);
+            fwrite(acc.data(), sizeof(COMPLEX), n, out);
+            for (int k = 0; k < n; k++) { acc[k].real = k; acc[k].imag = -2.0 * k; }
+            IFFTProcess(spec.data(), acc.data(), n);
+            fwrite(acc.data(), sizeof(COMPLEX), n, out);
+        }
     } else if (!strcmp(what, "fft")) {
         std::vector<COMPLEX> a(512), b(512);
         short bits[512];

@@ -84,26 +84,21 @@ void Bitrev(COMPLEX *in, short *bits, int n, COMPLEX *out)
     for (int k = 0; k < n; k++) out[k] = in[bits[k]];                    // :204-205
 }
 
+// The O(N^2) family: evaluated on the device as the reference writes the sums (any n, accumulating into the
+// caller's output like the reference, :168,:178,:154) -- jdsp_dft_direct_f64.
 void DFTProcess(short *in, COMPLEX *out, int n)
 {
-    std::vector<COMPLEX> a(n), b(n);
-    for (int i = 0; i < n; i++) { a[i].real = in[i]; a[i].imag = 0; }
-    FFTProcess(a.data(), b.data(), n, true);
-    for (int i = 0; i < n; i++) { out[i].real += b[i].real; out[i].imag += b[i].imag; }   // the reference accumulates (:168)
+    CK(jdsp_dft_direct_f64(JeicybooContext(), JDSP_DFT_I16, in, (double *)out, n, 1));
 }
 
 void IDFTProcess(COMPLEX *in, COMPLEX *out, int n)
 {
-    std::vector<COMPLEX> b(n);
-    FFTProcess(in, b.data(), n, false);
-    for (int i = 0; i < n; i++) { out[i].real += b[i].real; out[i].imag += b[i].imag; }   // :178
+    CK(jdsp_dft_direct_f64(JeicybooContext(), JDSP_IDFT, in, (double *)out, n, 1));
 }
 
 void IFFTProcess(COMPLEX *in, COMPLEX *out, int n)
 {
-    std::vector<COMPLEX> b(n);
-    FFTProcess(in, b.data(), n, false);
-    for (int i = 0; i < n; i++) { out[i].real += b[i].real / n; out[i].imag += b[i].imag / n; }   // :154
+    CK(jdsp_dft_direct_f64(JeicybooContext(), JDSP_IDFT_OVER_N, in, (double *)out, n, 1));
 }
 
 // ---- SpectralSubtraction_final.cpp / WienerFilter_final.cpp --------------------------------

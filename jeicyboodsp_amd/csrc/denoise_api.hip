@@ -85,6 +85,8 @@ int jdsp_denoise_set_option(jdsp_denoise *h, const char *name, long value)
 {
     if (!h || !name) return JDSP_EINVAL;
     if (!strcmp(name, "blocks_per_wave")) {
+        if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8)
+            return fail(h->ctx, JDSP_EINVAL, "jdsp_denoise_set_option: blocks_per_wave must be 0 (auto), 1, 2, 4 or 8");
         h->opt_k = (int)value;
         return JDSP_OK;
     }

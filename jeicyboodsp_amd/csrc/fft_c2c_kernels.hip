@@ -171,6 +171,56 @@ __global__ __launch_bounds__(64) void fft512_f64_kernel(const double2 *__restric
     }
 }
 
+// ---- DFTProcess / IDFTProcess / IFFTProcess (FFT:151-184): the definition-level O(N^2) sums ---------------
+// One thread per output bin k, the i loop in the reference's order, every product, sum and quotient rounded
+// on its own (no FMA contraction), the angle formed as the reference forms it -- ((2*PI)*i)*k/N with its
+// PI 3.14159265358 (FFT:15) -- and the result ACCUMULATED into what the caller left in `out` (the reference
+// adds into its output arrays and relies on the caller having zeroed them, :168,:178,:154).  Any n >= 1.
+// KIND 0: DFTProcess, int16 in (:162-173); 1: IDFTProcess, unnormalised (:175-184); 2: IFFTProcess, each
+// term `* 1 / (double)iFFTLen` (:151-160).
+template <int KIND>
+__global__ __launch_bounds__(256) void dft_direct_f64_kernel(const void *__restrict__ in_v, double2 *__restrict__ out, int n)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const double two_pi = __dmul_rn(2.0, 3.14159265358);
+    const double dn = (double)n;
+    double2 *dst = out + (size_t)blockIdx.y * n + k;
+    double re = dst->x, im = dst->y;
+    if (KIND == 0) {
+        const short *in = reinterpret_cast<const short *>(in_v) + (size_t)blockIdx.y * n;
+        for (int i = 0; i < n; i++) {
+            const double a = __ddiv_rn(__dmul_rn(__dmul_rn(two_pi, (double)i), (double)k), dn);
+            const double x = (double)in[i];
+            re = __dadd_rn(re, __dmul_rn(x, cos(a)));
+            im = __dadd_rn(im, __dmul_rn(x, -sin(a)));
+        }
+    } else {
+        const double2 *in = reinterpret_cast<const double2 *>(in_v) + (size_t)blockIdx.y * n;
+        for (int i = 0; i < n; i++) {
+            const double a = __ddiv_rn(__dmul_rn(__dmul_rn(two_pi, (double)i), (double)k), dn);
+            const double c = cos(a), s = sin(a);
+            const double2 z = in[i];
+            double tr = __dsub_rn(__dmul_rn(z.x, c), __dmul_rn(z.y, s));
+            double ti = __dadd_rn(__dmul_rn(z.x, s), __dmul_rn(z.y, c));
+            if (KIND == 2) { tr = __ddiv_rn(tr, dn); ti = __ddiv_rn(ti, dn); }     // (..) * 1 / (double)iFFTLen
+            re = __dadd_rn(re, tr);
+            im = __dadd_rn(im, ti);
+        }
+    }
+    *dst = make_double2(re, im);
+}
+
+int launch_dft_direct_f64(hipStream_t stream, int kind, const void *in, double2 *inout, int n, long batch)
+{
+    if (batch <= 0 || n <= 0) return 0;
+    const dim3 grid((unsigned)((n + 255) / 256), (unsigned)batch), block(256);
+    if (kind == 0) hipLaunchKernelGGL(dft_direct_f64_kernel<0>, grid, block, 0, stream, in, inout, n);
+    else if (kind == 1) hipLaunchKernelGGL(dft_direct_f64_kernel<1>, grid, block, 0, stream, in, inout, n);
+    else hipLaunchKernelGGL(dft_direct_f64_kernel<2>, grid, block, 0, stream, in, inout, n);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 int launch_bitrev_table(hipStream_t stream, short *table_dev, int n_fft, int bits)
 {
     hipLaunchKernelGGL(bitrev_table_kernel, dim3((n_fft + 255) / 256), dim3(256), 0, stream, table_dev, n_fft, bits);

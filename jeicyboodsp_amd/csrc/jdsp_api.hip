@@ -112,6 +112,7 @@ int jdsp_destroy(jdsp_ctx *ctx)
     if (ctx->pipe_out) (void)hipStreamDestroy(ctx->pipe_out);
     if (ctx->conv_tw4096) (void)hipFree(ctx->conv_tw4096);
     if (ctx->conv_tw8192) (void)hipFree(ctx->conv_tw8192);
+    if (ctx->switch_ev) (void)hipEventDestroy(ctx->switch_ev);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
     return JDSP_OK;
@@ -119,18 +120,39 @@ int jdsp_destroy(jdsp_ctx *ctx)
 
 const char *jdsp_last_error(const jdsp_ctx *ctx) { return ctx ? ctx->error.c_str() : g_create_error.c_str(); }
 
+// Work already enqueued on the stream the handle is leaving (create/reset memsets, the previous call's
+// state updates: overlap tail, run length, noise rows) must be visible to whatever is enqueued next on the
+// stream it moves to: record an event on the old stream and make the new one wait for it.  Nothing is done
+// when the stream does not change (the common case, and the only one inside a graph capture), nor when
+// either stream is being captured -- an event recorded outside a capture cannot order captured work, so
+// there the ordering stays the caller's (bench.py: wait_stream before and after the capture).
+static int switch_stream(jdsp_ctx *ctx, hipStream_t next)
+{
+    if (next == ctx->stream) return JDSP_OK;
+    hipStreamCaptureStatus a = hipStreamCaptureStatusNone, b = hipStreamCaptureStatusNone;
+    const bool ok_a = hipStreamIsCapturing(ctx->stream, &a) == hipSuccess;
+    const bool ok_b = hipStreamIsCapturing(next, &b) == hipSuccess;
+    if (!ok_a || !ok_b) (void)hipGetLastError();
+    if (ok_a && ok_b && a == hipStreamCaptureStatusNone && b == hipStreamCaptureStatusNone) {
+        JDSP_HIP(ctx, hipSetDevice(ctx->device));
+        if (!ctx->switch_ev) JDSP_HIP(ctx, hipEventCreateWithFlags(&ctx->switch_ev, hipEventDisableTiming));
+        JDSP_HIP(ctx, hipEventRecord(ctx->switch_ev, ctx->stream));
+        JDSP_HIP(ctx, hipStreamWaitEvent(next, ctx->switch_ev, 0));
+    }
+    ctx->stream = next;
+    return JDSP_OK;
+}
+
 int jdsp_set_stream(jdsp_ctx *ctx, void *hip_stream)
 {
     if (!ctx) return JDSP_EINVAL;
-    ctx->stream = (hipStream_t)hip_stream;
-    return JDSP_OK;
+    return switch_stream(ctx, (hipStream_t)hip_stream);
 }
 
 int jdsp_use_own_stream(jdsp_ctx *ctx)
 {
     if (!ctx) return JDSP_EINVAL;
-    ctx->stream = ctx->own_stream;
-    return JDSP_OK;
+    return switch_stream(ctx, ctx->own_stream);
 }
 
 int jdsp_set_option(jdsp_ctx *ctx, const char *name, long value)
@@ -283,6 +305,52 @@ int jdsp_fft_process_f64(jdsp_ctx *ctx, const double *in_host, double *out_host,
     if (!rc && (e = hipMemcpyAsync(out_host, d_out, bytes, hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess)
         rc = fail(ctx, JDSP_EHIP, "jdsp_fft_process_f64: D2H", e);
     if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess && !rc) rc = fail(ctx, JDSP_EHIP, "jdsp_fft_process_f64: sync", e);
+    (void)hipFree(d_in);
+    (void)hipFree(d_out);
+    return rc;
+}
+
+int jdsp_dft_direct_f64_dev(jdsp_ctx *ctx, int kind, const void *in_dev, double *inout_dev, int n, long batch)
+{
+    if (!ctx) return JDSP_EINVAL;
+    if (kind < JDSP_DFT_I16 || kind > JDSP_IDFT_OVER_N) return fail(ctx, JDSP_EINVAL, "jdsp_dft_direct_f64: kind");
+    if (n < 1 || batch < 0 || batch > 65535) return fail(ctx, JDSP_EINVAL, "jdsp_dft_direct_f64: n >= 1, 0 <= batch <= 65535");
+    if (batch == 0) return JDSP_OK;
+    if (!in_dev || !inout_dev) return fail(ctx, JDSP_EINVAL, "jdsp_dft_direct_f64: NULL buffer");
+    if ((uintptr_t)inout_dev & 15u || (kind != JDSP_DFT_I16 && ((uintptr_t)in_dev & 15u)))
+        return fail(ctx, JDSP_EINVAL, "jdsp_dft_direct_f64: complex buffers must be 16-byte aligned");
+    JDSP_HIP(ctx, hipSetDevice(ctx->device));
+    if (jdsp::launch_dft_direct_f64(ctx->stream, kind, in_dev, (double2 *)inout_dev, n, batch))
+        return fail(ctx, JDSP_EHIP, "dft_direct launch", hipGetLastError());
+    return JDSP_OK;
+}
+
+int jdsp_dft_direct_f64(jdsp_ctx *ctx, int kind, const void *in_host, double *inout_host, int n, long batch)
+{
+    if (!ctx) return JDSP_EINVAL;
+    if (kind < JDSP_DFT_I16 || kind > JDSP_IDFT_OVER_N) return fail(ctx, JDSP_EINVAL, "jdsp_dft_direct_f64: kind");
+    if (n < 1 || batch < 0 || batch > 65535) return fail(ctx, JDSP_EINVAL, "jdsp_dft_direct_f64: n >= 1, 0 <= batch <= 65535");
+    if (batch == 0) return JDSP_OK;
+    if (!in_host || !inout_host) return fail(ctx, JDSP_EINVAL, "jdsp_dft_direct_f64: NULL buffer");
+    JDSP_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t out_b = sizeof(double) * 2 * (size_t)n * (size_t)batch;
+    const size_t in_b = kind == JDSP_DFT_I16 ? sizeof(int16_t) * (size_t)n * (size_t)batch : out_b;
+    void *d_in = nullptr;
+    double *d_out = nullptr;
+    JDSP_HIP(ctx, hipMalloc(&d_in, in_b));
+    hipError_t e = hipMalloc((void **)&d_out, out_b);
+    if (e != hipSuccess) {
+        (void)hipFree(d_in);
+        return fail(ctx, JDSP_ENOMEM, "jdsp_dft_direct_f64: hipMalloc", e);
+    }
+    int rc = JDSP_OK;
+    if ((e = hipMemcpyAsync(d_in, in_host, in_b, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess ||
+        (e = hipMemcpyAsync(d_out, inout_host, out_b, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess)
+        rc = fail(ctx, JDSP_EHIP, "jdsp_dft_direct_f64: H2D", e);
+    if (!rc) rc = jdsp_dft_direct_f64_dev(ctx, kind, d_in, d_out, n, batch);
+    if (!rc && (e = hipMemcpyAsync(inout_host, d_out, out_b, hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess)
+        rc = fail(ctx, JDSP_EHIP, "jdsp_dft_direct_f64: D2H", e);
+    if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess && !rc) rc = fail(ctx, JDSP_EHIP, "jdsp_dft_direct_f64: sync", e);
     (void)hipFree(d_in);
     (void)hipFree(d_out);
     return rc;

@@ -18,6 +18,7 @@ struct jdsp_ctx {
     char name[64] = {0};
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;      // the stream work is enqueued on
+    hipEvent_t switch_ev = nullptr;    // orders the old stream's work before the new stream's (jdsp_set_stream)
     std::string error;
     int opt_stft_fpw = 0;              // 0 = auto
     int opt_stft_window = 0;           // 0 Hamming (the reference), 1 Hann -- jdsp_stft_* only
@@ -108,6 +109,7 @@ int launch_bitrev_table(hipStream_t stream, short *table_dev, int n_fft, int bit
 int launch_fft_process_f64(hipStream_t stream, const double2 *in, double2 *out, int n_fft, int log2n, long batch,
                            int forward, const double2 *tw);
 void fill_c2c_twiddles(double2 *t, int n_fft);
+int launch_dft_direct_f64(hipStream_t stream, int kind, const void *in, double2 *inout, int n, long batch);
 
 
 // denoise_kernels.hip

@@ -105,6 +105,21 @@ class Engine:
                                         x.size // n, int(forward)))
         return out
 
+    DFT_I16, IDFT, IDFT_OVER_N = 0, 1, 2
+
+    def dft_direct(self, kind, x, accumulate_into=None):
+        """DFTProcess / IDFTProcess / IFFTProcess (FFTAlgorithm_ver2.cpp:162-173 / :175-184 / :151-160): the
+        O(N^2) sums as the reference writes them, any length, ADDED to `accumulate_into` (default: zeros).
+        x: int16 [..., n] for DFT_I16, complex128 [..., n] otherwise.  Returns complex128 [..., n]."""
+        x = np.ascontiguousarray(x, np.int16 if kind == self.DFT_I16 else np.complex128)
+        n = x.shape[-1]
+        out = np.zeros(x.shape, np.complex128) if accumulate_into is None else \
+            np.ascontiguousarray(accumulate_into, np.complex128).copy()
+        assert out.shape == x.shape
+        self._ck(L.jdsp_dft_direct_f64(self._h, int(kind), x.ctypes.data_as(C.c_void_p),
+                                       out.ctypes.data_as(C.c_void_p), n, x.size // n))
+        return out
+
     # ---- PitchEstimation_method1.cpp ---------------------------------------------
     def pitch(self, pcm, prev_block=None, want_autocorr=False):
         """CalcPitch (PitchEstimation_method1.cpp:69-116) for every 512-sample block of pcm:

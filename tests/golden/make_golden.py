@@ -12,6 +12,11 @@ produced for them -- never reference source text.
                     IFFTProcess on seeded frames, and main()'s WAV round trip.
   fftalg_1024.npz   same translation unit with -DBLOCK_LEN=1024 (the only edit:
                     the #define at :16), Bitrev table + FFTProcess fwd/inv.
+  stft_1024.npz     the headline path pinned to the reference's OWN transform: seeded int16 frames
+  stft_512.npz      (hop n/2) x the applications' Hamming window (SpectralSubtraction_final.cpp:226,
+                    PI 3.141592) -> FFTProcess of the compiled FFTAlgorithm_ver2.cpp (BLOCK_LEN = n),
+                    i.e. SS:218-230 with the reference's in-tree FFT in FFTW's place (north_star:
+                    "FFTAlgorithm_ver2 feeding ...").  n = 1024 (BASELINE metric) and 512 (config 3 as worded).
   rir_taps.npz      the 69 non-zero taps (index, value) of FilterCoefficient.h's
                     rgdFirLPF_coefficients[7169] -- the filter DATA the native
                     fast-convolution configuration runs with.
@@ -97,6 +102,24 @@ def fftalg(block_len, n_frames, with_slow):
     print("fftalg_%d.npz" % block_len, {k: v.shape for k, v in out.items()})
 
 
+def stft(n, n_frames):
+    """SS:218-230 with FFTAlgorithm_ver2's FFTProcess as the transform."""
+    import math
+    ref = oracle_lib.load_ref(n)
+    assert ref is not None and ref.block_len == n
+    hop = n // 2
+    pcm = seeded_pcm(2000 + n, hop * (n_frames - 1) + n)
+    PI = 3.141592                                                      # SS:52
+    w = np.array([0.54 - 0.46 * math.cos(2 * PI * i / (n - 1)) for i in range(n)])   # SS:226, libm cos
+    spec = np.zeros((n_frames, n), np.complex128)
+    with quiet_stdout():
+        for f in range(n_frames):
+            fr = pcm[hop * f:hop * f + n].astype(np.float64) * w      # fcInputBefFFT[i][0] *= (...)
+            spec[f] = ref.fft_process(fr.astype(np.complex128), True)
+    np.savez_compressed(os.path.join(HERE, "stft_%d.npz" % n), pcm=pcm, hop=np.int32(hop), spec=spec)
+    print("stft_%d.npz" % n, pcm.shape, spec.shape)
+
+
 def rir_taps():
     txt = open(os.path.join(REF, "FilterCoefficient.h"), "rb").read().decode("latin-1")
     n = int(re.search(r"#define\s+FILTER_LENGTH\s+(\d+)", txt).group(1))
@@ -111,4 +134,6 @@ def rir_taps():
 if __name__ == "__main__":
     fftalg(512, 4, True)
     fftalg(1024, 2, False)
+    stft(1024, 6)
+    stft(512, 6)
     rir_taps()

@@ -57,6 +57,33 @@ def test_compat_denoise_per_block_calls(tmp_path, oracle, what, mode):
     assert np.abs(got.astype(np.int32) - want.astype(np.int32)).max() <= 1
 
 
+@pytest.mark.parametrize("n", [512, 12])
+def test_compat_slow_dft_family_accumulating(tmp_path, oracle, golden_dir, n):
+    """DFTProcess / IDFTProcess / IFFTProcess with the reference's signatures (FFTAlgorithm_ver2.cpp:151-184),
+    called with PRE-FILLED outputs (k, -2k): the reference accumulates.  n = 512 against the compiled
+    reference's golden outputs, n = 12 (not a power of two) against the oracle."""
+    g = np.load(os.path.join(golden_dir, "fftalg_512.npz"), allow_pickle=False)
+    pcm = g["pcm"][: 2 * 512] if n == 512 else g["pcm"][: 3 * n]
+    pcm.tofile(tmp_path / "in.raw")
+    run("compat_selftest", "dft", tmp_path / "in.raw", tmp_path / "out.bin", n)
+    got = np.fromfile(tmp_path / "out.bin", np.complex128).reshape(-1, 3, n)
+    k = np.arange(n)
+    pre = k - 2j * k
+    for b in range(got.shape[0]):
+        blk = pcm[b * n:(b + 1) * n]
+        if n == 512:
+            dft = g["dft"][b]
+        else:
+            dft = oracle.dft_process(blk)
+        want_dft = pre + dft
+        assert np.abs(got[b, 0] - want_dft).max() < 1e-10 * np.abs(want_dft).max()
+        # the selftest feeds ITS DFTProcess output (pre-fill included) to the two inverses
+        want_idft = pre + oracle.idft_process(got[b, 0])
+        want_ifft = pre + oracle.ifft_process(got[b, 0])
+        assert np.abs(got[b, 1] - want_idft).max() < 1e-10 * np.abs(want_idft).max()
+        assert np.abs(got[b, 2] - want_ifft).max() < 1e-10 * np.abs(want_ifft).max()
+
+
 def test_compat_fft_bitrev(tmp_path, oracle, golden_dir):
     g = np.load(os.path.join(golden_dir, "fftalg_512.npz"), allow_pickle=False)
     g["pcm"].tofile(tmp_path / "in.raw")
