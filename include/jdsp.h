@@ -70,6 +70,11 @@ int jdsp_set_stream(jdsp_ctx *ctx, void *hip_stream);
 int jdsp_use_own_stream(jdsp_ctx *ctx);
 /* Tuning knobs, by name; unknown names return JDSP_EINVAL.
  *   "stft.frames_per_wave"  consecutive frames one wavefront owns (0 = auto)
+ *   "stft.read_pass"        -1 (default, auto) / 0 / 1: before the hop-512 transform of a large batch, one
+ *                           read-only launch streams the PCM into the 256 MiB Infinity Cache, slab by slab, so
+ *                           that HBM sees a read stream and then a write stream instead of their 1 : 8 mix
+ *                           (65,536 frames whose PCM is in HBM: 98 us against 147 us; PCM that is already
+ *                           cache-resident pays 9 us for nothing -- 0 turns the pass off).  Results are identical.
  *   "stft.window"           window of jdsp_stft_*: 0 = the reference's Hamming
  *                           0.54-0.46cos(2*3.141592*i/(n-1)) (default), 1 = Hann 0.5-0.5cos(same).
  *                           The denoise / MFCC / pitch chains always use what the reference uses. */

@@ -163,6 +163,16 @@ int jdsp_set_option(jdsp_ctx *ctx, const char *name, long value)
         ctx->opt_stft_fpw = (int)value;
         return JDSP_OK;
     }
+    if (!strcmp(name, "stft.read_pass")) {
+        if (value < -1 || value > 1) return fail(ctx, JDSP_EINVAL, "stft.read_pass: -1 (auto), 0 or 1");
+        ctx->opt_stft_read_pass = (int)value;
+        return JDSP_OK;
+    }
+    if (!strcmp(name, "stft.read_pass_wg_per_cu")) {
+        if (value < 0 || value > 64) return fail(ctx, JDSP_EINVAL, "stft.read_pass_wg_per_cu: 0 (default) .. 64");
+        ctx->opt_stft_touch_wg = (int)value;
+        return JDSP_OK;
+    }
     if (!strcmp(name, "stft.window")) {
         if (value != 0 && value != 1) return fail(ctx, JDSP_EINVAL, "stft.window: 0 (Hamming) or 1 (Hann)");
         ctx->opt_stft_window = (int)value;
@@ -446,7 +456,8 @@ int jdsp_stft_i16_dev(jdsp_ctx *ctx, const int16_t *pcm_dev, long n_frames, int 
             return fail(ctx, JDSP_EHIP, "stft512 launch", hipGetLastError());
         return JDSP_OK;
     }
-    if (jdsp::launch_stft1024(ctx->stream, ctx->n_cu, ctx->opt_stft_fpw, pcm_dev, n_frames, hop, (float2 *)spec_dev, tab))
+    if (jdsp::launch_stft1024(ctx->stream, ctx->n_cu, ctx->opt_stft_fpw, pcm_dev, n_frames, hop, (float2 *)spec_dev, tab,
+                              ctx->opt_stft_read_pass, ctx->opt_stft_touch_wg))
         return fail(ctx, JDSP_EHIP, "stft1024 launch", hipGetLastError());
     return JDSP_OK;
 }

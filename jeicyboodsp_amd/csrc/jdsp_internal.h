@@ -22,6 +22,9 @@ struct jdsp_ctx {
     std::string error;
     int opt_stft_fpw = 0;              // 0 = auto
     int opt_stft_window = 0;           // 0 Hamming (the reference), 1 Hann -- jdsp_stft_* only
+    int opt_stft_read_pass = -1;       // read-only pass that pulls the PCM into the Infinity Cache before the transform:
+                                       // 0 never, 1 always, -1 auto (large hop-512 batches); stft_kernels.hip
+    int opt_stft_touch_wg = 0;         // tuning: workgroups per CU of that pass (0 = default)
     float2 *stft1024_table_hann = nullptr, *win512_hann = nullptr;
     float2 *stft1024_table_rect = nullptr;   // rectangular window: the partitioned convolver's forward frames
     // device tables, created on first use
@@ -95,7 +98,7 @@ int fail(jdsp_ctx *ctx, int code, const char *what, hipError_t e = hipSuccess);
 int stft1024_table_count();
 void fill_stft1024_table(float2 *host_table, int window_kind);
 int launch_stft1024(hipStream_t stream, int n_cu, int fpw_opt, const short *pcm, long n_frames, long hop, float2 *spec,
-                    const float2 *table);
+                    const float2 *table, int read_pass = 0, int touch_wg_per_cu = 0);
 
 
 int launch_stft1024_half(hipStream_t stream, const short *pcm, long n_frames, float2 *spec, long pitch,

@@ -397,17 +397,78 @@ static void launch_hop512(hipStream_t stream, const short *pcm, long n_frames, f
                        table);
 }
 
+// ---- read pass: pulls a PCM range into the Infinity Cache ahead of the transform ---------------------------------
+// The transform kernel above runs at the chip's store rate (88-90 us per 65,536 frames against 83 us for a
+// hipMemset of the 512 MiB of spectra) -- when its PCM comes out of the 256 MiB Infinity Cache, which is what a
+// benchmark that re-reads one buffer measures.  With the input in HBM, where a stream of audio is, the same
+// launch takes 147 us (profiles/r02_cold_input_probe.txt): a wave's loads queue behind the write stream, every wave
+// holds its slot for microseconds doing nothing, and HBM's 1 : 8 mix of reads and writes runs at 5.4-5.6 TB/s even
+// for a plain copy of this shape (tools/membw.hip, "COLD in": 107-112 us).  What was tried instead of this pass:
+// more frames per wave (K = 4: 131 us), more waves per SIMD (spills), touching the chunk D places ahead from inside
+// the transform (D = 1024, K = 4: 117 us), a software-pipelined persistent wave that loads chunk c+1 before it
+// stores chunk c, with hand-placed s_waitcnt (121-123 us cold, 99 us warm).  Separating the two streams in TIME wins:
+// one read-only launch streams the slab's PCM through (64 MiB in 9 us = 7.5 TB/s; reads allocate in the Infinity
+// Cache, the transform's nontemporal stores do not displace them), then the transform runs at its store rate:
+// 98 us per 65,536 cold frames.  A warm input pays the 9 us for nothing; "stft.read_pass" = 0 turns the pass off.
+constexpr long kReadPassSlabFrames = 65536;       // 64 MiB of PCM per slab
+constexpr long kReadPassMinFrames = 16384;        // auto mode: smaller batches live in L2 / Infinity Cache anyway
+
+__global__ __launch_bounds__(256) void pcm_touch_kernel(const u32x4 *__restrict__ p, long n16, unsigned int *__restrict__ sink)
+{
+    const long stride = (long)gridDim.x * 256;
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    unsigned int acc = 0;
+    for (; i + 3 * stride < n16; i += 4 * stride) {               // four 16-byte loads per lane in flight
+        const u32x4 a = p[i], b = p[i + stride], c = p[i + 2 * stride], d = p[i + 3 * stride];
+        acc ^= a.x ^ b.x ^ c.x ^ d.x;
+    }
+    for (; i < n16; i += stride) acc ^= p[i].x;
+    if (sink && acc == 0x9e3779b9u) *sink = acc;                   // keeps the loads alive; sink is NULL in every launch
+}
+
+static int launch_pcm_touch(hipStream_t stream, int n_cu, int wg_per_cu, const short *pcm, long n_samples)
+{
+    const long n16 = n_samples / 8;                                // whole 16-byte units (pcm is 16-byte aligned)
+    if (n16 <= 0) return 0;
+    long grid = (long)n_cu * (wg_per_cu > 0 ? wg_per_cu : 4);      // 4 x 256 threads x 4 loads of 16 B: 64 KB in flight per CU
+    const long need = (n16 + 255) / 256;
+    if (grid > need) grid = need;
+    hipLaunchKernelGGL(pcm_touch_kernel, dim3((unsigned)grid), dim3(256), 0, stream, reinterpret_cast<const u32x4 *>(pcm), n16,
+                       (unsigned int *)nullptr);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// One slab of the fast path: frames [0, n_frames) of `pcm` with K frames per wave.
+static void launch_hop512_any(hipStream_t stream, int fpw_opt, const short *pcm, long n_frames, float2 *spec,
+                              const float2 *table)
+{
+    switch (fpw_opt) {
+    case 1: launch_hop512<1>(stream, pcm, n_frames, spec, table); break;
+    case 2: launch_hop512<2>(stream, pcm, n_frames, spec, table); break;
+    case 3: launch_hop512<3>(stream, pcm, n_frames, spec, table); break;
+    case 4: launch_hop512<4>(stream, pcm, n_frames, spec, table); break;
+    default: launch_hop512<JDSP_STFT_K>(stream, pcm, n_frames, spec, table); break;
+    }
+}
+
+// read_pass: 0 never, 1 always, -1 auto (batches of kReadPassMinFrames frames or more).  touch_wg_per_cu: 0 = default.
 int launch_stft1024(hipStream_t stream, int n_cu, int fpw_opt, const short *pcm, long n_frames, long hop,
-                    float2 *spec, const float2 *table)
+                    float2 *spec, const float2 *table, int read_pass, int touch_wg_per_cu)
 {
     if (n_frames <= 0) return 0;
     if (hop == 512 && ((uintptr_t)pcm & 15u) == 0) {
-        switch (fpw_opt) {
-        case 1: launch_hop512<1>(stream, pcm, n_frames, spec, table); break;
-        case 2: launch_hop512<2>(stream, pcm, n_frames, spec, table); break;
-        case 3: launch_hop512<3>(stream, pcm, n_frames, spec, table); break;
-        case 4: launch_hop512<4>(stream, pcm, n_frames, spec, table); break;
-        default: launch_hop512<JDSP_STFT_K>(stream, pcm, n_frames, spec, table); break;
+        const bool touch = read_pass > 0 || (read_pass < 0 && n_frames >= kReadPassMinFrames);
+        if (!touch) {
+            launch_hop512_any(stream, fpw_opt, pcm, n_frames, spec, table);
+        } else {
+            // slab by slab, so that a slab's PCM (64 MiB) is a quarter of the Infinity Cache whatever the batch is
+            for (long f0 = 0; f0 < n_frames; f0 += kReadPassSlabFrames) {
+                const long nf = n_frames - f0 < kReadPassSlabFrames ? n_frames - f0 : kReadPassSlabFrames;
+                if (launch_pcm_touch(stream, n_cu, touch_wg_per_cu, pcm + f0 * 512, 512 * (nf + 1))) return -1;
+                // behind the read pass one frame per wave is the fastest (98.5 us per 65,536 cold frames against
+                // 100-102 for two and 108-110 for three, profiles/r02_cold_input_probe.txt)
+                launch_hop512_any(stream, fpw_opt > 0 ? fpw_opt : 1, pcm + f0 * 512, nf, spec + f0 * 1024, table);
+            }
         }
     } else {
         // short-lived waves here too: a wave that loops reads its next frame after its stores

@@ -170,3 +170,29 @@ def test_partitioned_convolver_equals_the_8192_point_kernel_at_4096_blocks(eng, 
     assert oa.shape == ob.shape == ((4096 - 7) * 1024,)
     assert np.abs(pa - pb).max() < 1e-5 * np.abs(pb).max()
     assert np.abs(oa.astype(np.int32) - ob.astype(np.int32)).max() <= 1
+
+
+def test_stft_read_pass_slabs_do_not_change_a_single_bit(eng, oracle):
+    """"stft.read_pass": the read-only launch in front of the transform (and the slab loop of a batch larger than
+    one 65,536-frame slab) only moves bytes into the Infinity Cache -- spectra with the pass on (default for
+    large batches), forced on, and off must be bit-identical, across a slab boundary too; spot-checked against
+    the oracle on both sides of the boundary."""
+    import torch
+    n = B + 4099                                     # two slabs, the second one ragged
+    rng = np.random.default_rng(77)
+    pcm = np.clip(np.rint(rng.normal(0, 3000, 512 * (n + 1))), -32768, 32767).astype(np.int16)
+    d = torch.from_numpy(pcm).cuda()
+    outs = []
+    for rp in (0, -1, 1):
+        eng.set_option("stft.read_pass", rp)
+        outs.append(eng.stft(d, n))
+        torch.cuda.synchronize()
+    eng.set_option("stft.read_pass", -1)
+    assert torch.equal(torch.view_as_real(outs[0]), torch.view_as_real(outs[1]))
+    assert torch.equal(torch.view_as_real(outs[0]), torch.view_as_real(outs[2]))
+    for f0 in (B - 256, n - 512):
+        want = oracle.stft(pcm[512 * f0:512 * (f0 + 513)], 512)
+        got = outs[1][f0:f0 + 512].cpu().numpy().astype(np.complex128)
+        assert (np.abs(got - want) / np.abs(want).max(axis=1, keepdims=True)).max() < TOL
+    with pytest.raises(Exception):
+        eng.set_option("stft.read_pass", 2)

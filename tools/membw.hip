@@ -28,6 +28,10 @@ template<bool NT> __global__ __launch_bounds__(64) void copy_frames(const f32x4*
 #pragma unroll
     for(int j=0;j<8;j++){ if(NT) __builtin_nontemporal_store(x,d+64*j); else d[64*j]=x; } }
 }
+// E: the reads alone (1 KiB per wave), result folded into one never-taken store
+__global__ __launch_bounds__(64) void read_frames(const f32x4* in, f32x4* out, long nframes){
+  long f=blockIdx.x; f32x4 x=in[f*64+threadIdx.x]; if(x.x==12345.678f) out[f]=x;
+}
 // D: 256-thread blocks, block owns consecutive frames, waves interleave frames
 template<bool NT> __global__ __launch_bounds__(256) void fill_frames_wg(f32x4* out, long nframes, int fpb, float v){
   long f0=(long)blockIdx.x*fpb, f1=f0+fpb; if(f1>nframes) f1=nframes;
@@ -54,6 +58,17 @@ int main(){
   for(int fpb: {16,64,256}){ char nm[64]; int grid=(B+fpb-1)/fpb;
     snprintf(nm,64,"D wg256 fpb=%d",fpb); rep(nm,timeit([&]{fill_frames_wg<false><<<grid,256>>>(out,B,fpb,1.f);}),obytes);
     snprintf(nm,64,"D wg256 NT fpb=%d",fpb); rep(nm,timeit([&]{fill_frames_wg<true><<<grid,256>>>(out,B,fpb,1.f);}),obytes); }
+  // COLD input: the same copy shape rotating over 6 distinct 64 MiB inputs (384 MiB > the 256 MiB Infinity Cache),
+  // so every launch's reads come from HBM; and the reads alone.
+  {
+    f32x4* ins[6]; for(int i=0;i<6;i++){ CK(hipMalloc(&ins[i],ibytes)); CK(hipMemset(ins[i],0,ibytes)); }
+    int rot=0;
+    for(int fpw: {1,2,4,8}){ char nm[64]; int grid=(B+fpw-1)/fpw;
+      snprintf(nm,64,"C copy frames NT fpw=%d COLD in",fpw); rep(nm,timeit([&]{copy_frames<true><<<grid,64>>>(ins[(rot++)%6],out,B,fpw);},60),obytes+ibytes);
+      snprintf(nm,64,"C copy frames NT fpw=%d warm in",fpw); rep(nm,timeit([&]{copy_frames<true><<<grid,64>>>(ins[0],out,B,fpw);},60),obytes+ibytes); }
+    rep("E read-only 64MiB COLD (fpw=1)",timeit([&]{read_frames<<<B,64>>>(ins[(rot++)%6],out,B);},60),ibytes);
+    rep("E read-only 64MiB warm (fpw=1)",timeit([&]{read_frames<<<B,64>>>(ins[0],out,B);},60),ibytes);
+  }
   // plain float4 copy 512 MiB -> 512 MiB for calibration against the guide's 6.29 TB/s
   f32x4* src; CK(hipMalloc(&src,obytes)); CK(hipMemset(src,0,obytes));
   rep("hipMemcpyDtoD 512MiB (r+w)",timeit([&]{hipMemcpyAsync(out,src,obytes,hipMemcpyDeviceToDevice,0);}),2.0*obytes);
