@@ -271,6 +271,18 @@ int jdsp_mvdr_process_dev(jdsp_mvdr *h, const int16_t *left_dev, const int16_t *
 int jdsp_mvdr_process(jdsp_mvdr *h, const int16_t *left_host, const int16_t *right_host, long n_blocks,
                       int16_t *out_host, float *precast_host, long *n_out_blocks);
 int jdsp_mvdr_corr(jdsp_mvdr *h, double *corr4_host);
+/* The program's two helper functions on their own, for callers that keep main()'s structure -- or do not follow
+ * it (jeicyboodsp_amd/compat: EstimateSpatialCorrMtx, ProcessMVDR with the reference's signatures):
+ *   jdsp_mvdr_estimate_corr  EstimateSpatialCorrMtx (:244-270) for n_frames frames of 1024 samples per channel
+ *                            ([previous block, block], rgsTempBufferL/R), every frame's contribution ADDED to the
+ *                            caller's rgdSpatialCorr (4 doubles, row-major).  Touches no stream state.
+ *   jdsp_mvdr_apply          ProcessMVDR (:124-205) for n_blocks blocks with the CALLER's rgdSpatialCorr instead of
+ *                            the handle's own VAD + accumulation: only the two keep buffers (:130-131) and the call
+ *                            counter (:137) of the handle are used and advanced. */
+int jdsp_mvdr_estimate_corr(jdsp_mvdr *h, const int16_t *left_frames_host, const int16_t *right_frames_host, long n_frames,
+                            double *corr4_inout_host);
+int jdsp_mvdr_apply(jdsp_mvdr *h, const int16_t *left_host, const int16_t *right_host, long n_blocks,
+                    const double *corr4_host, int16_t *out_host, float *precast_host, long *n_out_blocks);
 /* Sharded MVDR (multi-GPU): the rank owns global blocks [b0, b1) of a stream of n_total
  * blocks; the ext buffers hold global blocks [ext0, b1), ext0 = max(b0 - 1, 0).  shard_vad ->
  * flags_own; all-gather -> flags_all; shard_summary -> sum4 (this rank's contribution to
@@ -329,6 +341,17 @@ int jdsp_mfcc_frames_dev(jdsp_mfcc *h, const int16_t *pcm_dev, const int64_t *fr
 int jdsp_mfcc_frames(jdsp_mfcc *h, const int16_t *pcm_host, long n_samples, const int64_t *frame_start_host,
                      long n_frames, double *feats_host);
 
+/* The sub-steps of MFCCFeatureExtraction as functions of their own, for callers that keep the reference's
+ * structure (jeicyboodsp_amd/compat: MelFilterBank, DCT, Liftering with the reference's signatures).  FP64 and the
+ * reference's operation order; n_rows independent rows per call; host pointers.
+ *   MelFilterBank (:154-174): abs = |X| of the first n_fft/2 bins per row -> mel = ln of the n_chan channel sums
+ *   DCT           (:176-183): cep[n_cep] += sqrt(2/C) sum_k mel[k-1] cos(PI i (k-0.5)/C) -- ACCUMULATES into cep like
+ *                             the reference (its caller zeroes dMFCCFeature first, :224)
+ *   Liftering     (:185-192): cep[i-1] *= 1 + 0.5 L sin(PI i / L), in place */
+int jdsp_mfcc_melfilterbank(jdsp_mfcc *h, const double *abs_host, long n_rows, double *mel_host);
+int jdsp_mfcc_dct(jdsp_mfcc *h, const double *mel_host, long n_rows, double *cep_inout_host);
+int jdsp_mfcc_liftering(jdsp_mfcc *h, double *cep_inout_host, long n_rows);
+
 /* ---- GMM scoring / HMM recursion on MFCC vectors ------------- */
 /* GMMAlgorithm_Test_Auto_ver2.cpp and Viterbi_version1.cpp consume the 12-double vectors the MFCC program
  * writes (MFCC:99); here they are read where jdsp_mfcc_frames_dev left them, in HBM.  The parameter records
@@ -366,6 +389,13 @@ int jdsp_gmm_score_dev(jdsp_gmm *h, const double *feats_dev, long n_frames, cons
                        long n_utts, double *scores_dev, int *best_dev);
 int jdsp_gmm_score(jdsp_gmm *h, const double *feats_host, const int64_t *utt_first_host, long n_utts,
                    double *scores_host, int *best_host);
+
+/* probability() (GMMAlgorithm_Test_Auto_ver2.cpp:164-236, the live branch :216-235; = Viterbi_version1.cpp:248-267)
+ * on its own: the density of n 12-double vectors under ONE mixture component given as the reference passes it --
+ * pdMean (12 doubles, first 4 read), rgdCovariance[12][12] (diagonal entries 0..3 read), rgdEigenVector[12][4].
+ * FP64, the reference's operation order.  Host pointers. */
+int jdsp_gmm_probability(jdsp_ctx *ctx, const double *feats_host, long n, const double *mean12, const double *cov144,
+                         const double *eig48, double *prob_host);
 
 typedef struct jdsp_hmm jdsp_hmm;
 /* models: n_models (1..1024) six-state records; log(transProb) is taken here, on the host (Viterbi:196). */

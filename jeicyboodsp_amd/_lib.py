@@ -87,6 +87,10 @@ def _load():
         "jdsp_mfcc_destroy": (i, [vp]),
         "jdsp_mfcc_tables": (i, [vp, vp, vp, vp]),
         "jdsp_mfcc_frames_dev": (i, [vp, vp, vp, l, vp]),
+        "jdsp_mfcc_melfilterbank": (i, [vp, vp, l, vp]),
+        "jdsp_mfcc_dct": (i, [vp, vp, l, vp]),
+        "jdsp_mfcc_liftering": (i, [vp, vp, l]),
+        "jdsp_gmm_probability": (i, [vp, vp, l, vp, vp, vp, vp]),
         "jdsp_mfcc_frames": (i, [vp, vp, l, vp, l, vp]),
         "jdsp_fastconv_create": (i, [vp, vp, i, i, i, C.POINTER(vp)]),
         "jdsp_fastconv_destroy": (i, [vp]),
@@ -109,6 +113,8 @@ def _load():
         "jdsp_mvdr_process_dev": (i, [vp, vp, vp, l, vp, vp, C.POINTER(l)]),
         "jdsp_mvdr_process": (i, [vp, vp, vp, l, vp, vp, C.POINTER(l)]),
         "jdsp_mvdr_corr": (i, [vp, vp]),
+        "jdsp_mvdr_estimate_corr": (i, [vp, vp, vp, l, vp]),
+        "jdsp_mvdr_apply": (i, [vp, vp, vp, l, vp, vp, vp, C.POINTER(l)]),
         "jdsp_denoise_shard_vad_dev": (i, [vp, vp, l, l, l, l, vp]),
         "jdsp_denoise_shard_summary_dev": (i, [vp, vp, vp]),
         "jdsp_denoise_shard_rows_dev": (i, [vp, vp, i, i, vp]),

@@ -1,5 +1,5 @@
 // compat_mvdr_selftest.cpp -- BeamForming_MVDR_ver1.cpp's main() loop (:83-109) in structure, on the per-block
-// functions of jeicyboo_compat_mvdr.h.  usage: compat_mvdr_selftest left.raw right.raw out.bin
+// functions of jeicyboo_compat_mvdr.h.  usage: compat_mvdr_selftest left.raw right.raw out.bin [ooo]
 // out.bin: the int16 blocks the loop writes, then the final rgdSpatialCorr (4 doubles).
 #include <cstdio>
 #include <cstring>
@@ -8,8 +8,39 @@
 
 #define BLOCK_LEN 512
 
+// "ooo" mode: the two functions called OUT of main()'s order.  ProcessMVDR on blocks 0..2 with a hand-set matrix and
+// no estimate at all; then EstimateSpatialCorrMtx on the frames [block 3, block 4] and [block 7, block 5] (not even
+// consecutive blocks) into that pre-filled matrix; then ProcessMVDR on blocks 3..5 with the result.
+static int out_of_order(FILE *l, FILE *r, FILE *w)
+{
+    static short L[8][BLOCK_LEN], R[8][BLOCK_LEN];
+    for (int b = 0; b < 8; b++)
+        if (fread(L[b], sizeof(short), BLOCK_LEN, l) != BLOCK_LEN || fread(R[b], sizeof(short), BLOCK_LEN, r) != BLOCK_LEN) return 1;
+    double corr[2][2] = {{4.0e6, 1.5e5}, {-2.5e5, 3.0e6}};
+    short out[BLOCK_LEN], tl[2 * BLOCK_LEN], tr[2 * BLOCK_LEN];
+    for (int b = 0; b < 3; b++)
+        if (ProcessMVDR(L[b], R[b], BLOCK_LEN, out, 0.0, corr)) fwrite(out, sizeof(short), BLOCK_LEN, w);
+    const int pairs[2][2] = {{3, 4}, {7, 5}};
+    for (auto &p : pairs) {
+        memcpy(tl, L[p[0]], sizeof(L[0])); memcpy(tl + BLOCK_LEN, L[p[1]], sizeof(L[0]));
+        memcpy(tr, R[p[0]], sizeof(R[0])); memcpy(tr + BLOCK_LEN, R[p[1]], sizeof(R[0]));
+        EstimateSpatialCorrMtx(tl, tr, 2, corr, 2 * BLOCK_LEN);
+    }
+    for (int b = 3; b < 6; b++)
+        if (ProcessMVDR(L[b], R[b], BLOCK_LEN, out, 0.0, corr)) fwrite(out, sizeof(short), BLOCK_LEN, w);
+    fwrite(corr, sizeof(double), 4, w);
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
+    if (argc == 5 && !strcmp(argv[4], "ooo")) {
+        FILE *l = fopen(argv[1], "rb"), *r = fopen(argv[2], "rb"), *w = fopen(argv[3], "wb");
+        if (!l || !r || !w) return 1;
+        const int rc = out_of_order(l, r, w);
+        fclose(l); fclose(r); fclose(w);
+        return rc;
+    }
     if (argc != 4) return 1;
     FILE *fpRead1 = fopen(argv[1], "rb"), *fpRead2 = fopen(argv[2], "rb"), *fpWrite = fopen(argv[3], "wb");
     if (!fpRead1 || !fpRead2 || !fpWrite) return 1;

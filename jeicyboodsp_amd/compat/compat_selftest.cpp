@@ -1,6 +1,6 @@
 // compat_selftest.cpp -- drives the reference-signature functions exactly the way the
 // reference main()s do (one block per call) and dumps what they return, for tests/ to compare
-// with the CPU checker.  usage: compat_selftest <ss|wf|conv|mfcc|pitch|awgn|fft|dft|gmm|hmm> in.raw out.bin [taps.f64 | params.bin]
+// with the CPU checker.  usage: compat_selftest <ss|wf|conv|mfcc|mfccsteps|pitch|awgn|fft|dft|gmm|prob|hmm> in.raw out.bin [taps.f64 | params.bin]
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -97,6 +97,39 @@ int main(int argc, char **argv)
             fwrite(&s, 8, 1, out);
         }
         fclose(fp);
+    } else if (!strcmp(what, "mfccsteps")) {
+        // in.raw = raw double rows of 512 magnitudes (dAbs).  Per row, the tail of MFCCFeatureExtraction's body
+        // (:223-226): MelFilterBank, memset, DCT, Liftering -- and once more with a PRE-FILLED feature array to show
+        // that DCT accumulates.  Output per row: 38 + 12 + 12 doubles.
+        const size_t rows = pcm.size() * sizeof(short) / sizeof(double) / 512;
+        MelFilterBankInit();
+        for (size_t r = 0; r < rows; r++) {
+            double *dAbs = reinterpret_cast<double *>(pcm.data()) + 512 * r;
+            double mel[38], feat[12], pre[12];
+            MelFilterBank(dAbs, mel);
+            memset(feat, 0, sizeof(feat));
+            DCT(mel, feat);
+            Liftering(feat);
+            for (int i = 0; i < 12; i++) pre[i] = 100.0 + i;
+            DCT(mel, pre);
+            fwrite(mel, 8, 38, out);
+            fwrite(feat, 8, 12, out);
+            fwrite(pre, 8, 12, out);
+        }
+    } else if (!strcmp(what, "prob")) {
+        // in.raw = raw double[12] vectors, argv[4] = GMMParameter records: probability() of every vector under every
+        // mixture of the first record, the way Recognition's inner loop calls it (GMMTest:155-157)
+        if (argc < 5) return 1;
+        const size_t n = pcm.size() * sizeof(short) / sizeof(double) / 12;
+        FILE *fp = fopen(argv[4], "rb");
+        GMMParameter g;
+        if (!fp || fread(&g, sizeof(g), 1, fp) != 1) return 1;
+        fclose(fp);
+        for (size_t i = 0; i < n; i++)
+            for (int k = 0; k < 4; k++) {
+                const double p = probability(reinterpret_cast<double *>(pcm.data()) + 12 * i, g.mean[k], g.covariance[k], g.eigenVector[k]);
+                fwrite(&p, 8, 1, out);
+            }
     } else if (!strcmp(what, "dft")) {
         // DFTProcess / IDFTProcess / IFFTProcess (FFTAlgorithm_ver2.cpp:151-184) the way the commented-out
         // call sites (:74,:76) use them, n = argv[4] (default 512; any n, not only powers of two).  The output

@@ -185,6 +185,26 @@ bool MFCCFeatureExtraction(short *in, double (*feat)[12])
     return true;
 }
 
+// The three sub-steps with the reference's own signatures (MFCC:40-42): a caller that keeps
+// MFCCFeatureExtraction's body (its |X| loop, memset, then these three calls, :218-226) links unchanged.
+void MelFilterBank(double *dAbs, double *dMelFiltered)                                   // :154
+{
+    if (!g_mfcc) MelFilterBankInit();
+    CK(jdsp_mfcc_melfilterbank(g_mfcc, dAbs, 1, dMelFiltered));                         // reads dAbs[0..511], writes 38
+}
+
+void DCT(double *dMelFiltered, double *dMFCCFeature)                                     // :176 (accumulates)
+{
+    if (!g_mfcc) MelFilterBankInit();
+    CK(jdsp_mfcc_dct(g_mfcc, dMelFiltered, 1, dMFCCFeature));
+}
+
+void Liftering(double *dMFCCFeature)                                                     // :185
+{
+    if (!g_mfcc) MelFilterBankInit();
+    CK(jdsp_mfcc_liftering(g_mfcc, dMFCCFeature, 1));
+}
+
 // ---- PitchEstimation_method1.cpp ------------------------------------------------------------
 void CalcPitch(short *in, int n)
 {
@@ -220,6 +240,13 @@ static std::vector<double> gather_rows(double **rows, int n)
     std::vector<double> x((size_t)(n > 0 ? n : 0) * 12);
     for (int i = 0; i < n; i++) memcpy(&x[(size_t)i * 12], rows[i], 12 * sizeof(double));   // dpTestBuf[i][0..11]
     return x;
+}
+
+double probability(double *pdFeature, double *pdMean, double rgdCovariance[12][12], double rgdEigenVector[12][4])   // GMMTest:164
+{
+    double p = 0;
+    CK(jdsp_gmm_probability(JeicybooContext(), pdFeature, 1, pdMean, &rgdCovariance[0][0], &rgdEigenVector[0][0], &p));
+    return p;
 }
 
 double Recognition(double **rows, GMMParameter *param, int n)

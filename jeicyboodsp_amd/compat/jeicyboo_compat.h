@@ -49,8 +49,10 @@ extern int rgdFiBins[512];             // :35
 extern double rgdMelFreqs[38 + 1];     // :36
 void MelFilterBankInit();                                                                     // :118
 bool MFCCFeatureExtraction(short *rgsInputBuffer, double (*dMFCCFeature)[12]);                // :194
-// MelFilterBank (:154), DCT (:176) and Liftering (:185) are fused into MFCCFeatureExtraction's
-// kernel and are not exported separately.
+// The sub-steps on their own (MFCCFeatureExtraction's kernel fuses them; these are for callers that keep its body):
+void MelFilterBank(double *dAbs, double *dMelFiltered);                                      // :154  dAbs[512] -> 38 ln sums
+void DCT(double *dMelFiltered, double *dMFCCFeature);                                        // :176  ACCUMULATES into 12
+void Liftering(double *dMFCCFeature);                                                        // :185  in place
 
 // ---- PitchEstimation_method1.cpp:31 --------------------------------------------------------
 // Prints the reference's "Estimation arg %d , dMin %f pitch %f" line (:109); the lag and the
@@ -70,13 +72,15 @@ const double *JeicybooLastAutoCorrelation(void);                                
 // ---- GMMAlgorithm_Test_Auto_ver2.cpp:29-34,:44 / Viterbi_version1.cpp:30-40,:49 -------------
 // The parameter records are the C ABI's (same layout as the reference's structs).  One call scores one
 // utterance against one record; the class loop of main() (GMMTest:113-127) calls Recognition once per
-// class -- jdsp_gmm_score does all classes and all utterances in one launch.  probability() (GMMTest:164)
-// is fused into the kernels and not exported; HMMRecognition prints what the reference prints
+// class -- jdsp_gmm_score does all classes and all utterances in one launch.  probability() (GMMTest:43,:164)
+// keeps its signature too (one vector, one mixture component per call); HMMRecognition prints what the reference prints
 // (Viterbi:222-231), the decoded states as integers (the reference passes doubles to %d there).
 #ifndef JEICYBOO_NO_GMM_TYPEDEFS
 typedef jdsp_gmm_param GMMParameter;
 typedef jdsp_hmm_param HMMParameter;
 #endif
+double probability(double *pdFeature, double *pdMean, double rgdCovariance[12][12],
+                   double rgdEigenVector[12][4]);                                               // GMMTest:43,:164
 double Recognition(double **dpTestBuf, GMMParameter *pGmmParameter, int iFileLen);              // GMMTest:151
 double HMMRecognition(double **dpTestBuf, HMMParameter *pHmmParameter, int iFileLen);           // Viterbi:157
 

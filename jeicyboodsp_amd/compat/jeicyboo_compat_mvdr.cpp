@@ -41,22 +41,28 @@ bool VoiceActivityDetection(short *block, int n)
     return e > 716800;                                    // dEnergy = sum / 1024 > THRESHOLD_OF_ENERGY 700 (:233)
 }
 
-void EstimateSpatialCorrMtx(short *, short *, int, double (*)[2], int n)
+static jdsp_mvdr *handle(double d_time)
 {
-    // the accumulation of :263-268 happens inside the handle when ProcessMVDR is given this block (see the header)
-    if (n != 1024) { fprintf(stderr, "EstimateSpatialCorrMtx: iFrameCount must be 1024\n"); abort(); }
-}
-
-bool ProcessMVDR(short *left, short *right, int n, short *out, double d_time, double (*corr)[2])
-{
-    if (n != 512) { fprintf(stderr, "ProcessMVDR: iBlockLen must be 512\n"); abort(); }
     if (g_h && d_time != g_dtime) JeicybooMvdrReset();
     if (!g_h) {
         CK(jdsp_mvdr_create(context(), d_time, &g_h));
         g_dtime = d_time;
     }
+    return g_h;
+}
+
+// :244-270 -- the frame's contribution is ADDED to the caller's rgdSpatialCorr, whatever the caller did before
+void EstimateSpatialCorrMtx(short *temp_l, short *temp_r, int, double (*corr)[2], int n)
+{
+    if (n != 1024) { fprintf(stderr, "EstimateSpatialCorrMtx: iFrameCount must be 1024\n"); abort(); }
+    CK(jdsp_mvdr_estimate_corr(handle(g_dtime), temp_l, temp_r, 1, &corr[0][0]));
+}
+
+// :124-205 -- weights from the CALLER's rgdSpatialCorr (read, never written); statics = the handle's keep buffers
+bool ProcessMVDR(short *left, short *right, int n, short *out, double d_time, double (*corr)[2])
+{
+    if (n != 512) { fprintf(stderr, "ProcessMVDR: iBlockLen must be 512\n"); abort(); }
     long n_out = 0;
-    CK(jdsp_mvdr_process(g_h, left, right, 1, out, nullptr, &n_out));
-    if (corr) CK(jdsp_mvdr_corr(g_h, &corr[0][0]));
-    return n_out > 0;                                     // :201-204: nothing is written for the first block
+    CK(jdsp_mvdr_apply(handle(d_time), left, right, 1, &corr[0][0], out, nullptr, &n_out));
+    return n_out > 0;                                     // :201-204: false for the first block
 }

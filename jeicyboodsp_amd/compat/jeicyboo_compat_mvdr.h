@@ -2,13 +2,11 @@
 // A separate library (libjeicyboo_compat_mvdr.so): this program's VoiceActivityDetection has the same name and
 // signature as the SS / Wiener one in jeicyboo_compat.h but tests the energy only (:233).
 //
-// The reference main() (:83-109) drives the three functions in a fixed protocol: VAD on the left block, run
-// length, EstimateSpatialCorrMtx on [previous block, block] from the second block of a noise run on, then
-// ProcessMVDR with the matrix.  The engine's stream handle (jdsp_mvdr) keeps that whole protocol as its state, so
-// here ProcessMVDR feeds the block to the handle -- which runs the same VAD, run length and accumulation -- and
-// then writes the handle's matrix into the caller's rgdSpatialCorr; EstimateSpatialCorrMtx itself only checks its
-// arguments.  A caller that follows main()'s protocol (the only one the reference has) sees the reference's outputs
-// and, after every ProcessMVDR, the reference's matrix.
+// Each function does what the reference's does, on its own: EstimateSpatialCorrMtx transforms the caller's two
+// 1024-sample frames on the GPU and ADDS their contribution to the caller's rgdSpatialCorr (:263-268);
+// ProcessMVDR computes its weights from the caller's rgdSpatialCorr (:154-171) and keeps only the reference's own
+// statics (the two 511-sample keep buffers and the call counter, :130-131,:137) in a handle.  They can be called
+// in main()'s order (:83-109) or in any other.
 #ifndef JEICYBOO_COMPAT_MVDR_H
 #define JEICYBOO_COMPAT_MVDR_H
 

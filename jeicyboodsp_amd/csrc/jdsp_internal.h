@@ -169,6 +169,11 @@ int launch_mvdr(hipStream_t s, const short *left, const short *right, long n_blo
                 const MvdrState *st_in, MvdrState *st_out, const int *events, const DenoisePlan *plan,
                 const int *ver_base, const unsigned long long *snap_mask, double *delta, double *rver,
                 const double2 *steer, const float2 *table, short *out, float *precast);
+int launch_mvdr_corr_total(hipStream_t s, const short *left, const short *right, long n_blocks, const MvdrState *st_in,
+                           const int *events, const DenoisePlan *plan, const float2 *table, double *delta, double *total);
+int launch_mvdr_apply(hipStream_t s, const short *left, const short *right, long n_blocks, long calls_before,
+                      const MvdrState *st_in, MvdrState *st_out, const int *ver_base, const unsigned long long *snap_mask,
+                      const double *rver, const double2 *steer, const float2 *table, short *out, float *precast);
 int launch_mvdr_shard_summary(hipStream_t s, const short *left_ext, const short *right_ext, long n_ext, long ext0,
                               long b0, long b1, const MvdrState *zero_state, const int *events,
                               const DenoisePlan *plan, const int *ver_base, const unsigned long long *snap_mask,
@@ -236,6 +241,10 @@ struct jdsp_mfcc {
     void *blob = nullptr;                 // one device allocation holding every table
     std::vector<double> mel_freqs, fbank;
     std::vector<int> fi_bins;
+    // FP64 tables of the separately callable sub-steps (stage_api.hip), built on first use
+    void *stage_blob = nullptr;
+    const double *stage_fb = nullptr, *stage_cos = nullptr, *stage_lift = nullptr;
+    const int *stage_fi = nullptr;
 };
 
 struct jdsp_gmm {

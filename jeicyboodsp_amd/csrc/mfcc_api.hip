@@ -129,6 +129,7 @@ int jdsp_mfcc_destroy(jdsp_mfcc *h)
     (void)hipSetDevice(h->ctx->device);
     (void)hipStreamSynchronize(h->ctx->stream);
     if (h->blob) (void)hipFree(h->blob);
+    if (h->stage_blob) (void)hipFree(h->stage_blob);
     delete h;
     return JDSP_OK;
 }

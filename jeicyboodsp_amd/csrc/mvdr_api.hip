@@ -242,6 +242,99 @@ int jdsp_mvdr_shard_finish_dev(jdsp_mvdr *h, const double *sums_all_dev, int wor
     return JDSP_OK;
 }
 
+/* ---- the program's two helper functions on their own (compat: EstimateSpatialCorrMtx, ProcessMVDR) ---------- */
+int jdsp_mvdr_estimate_corr(jdsp_mvdr *h, const int16_t *left_frames_host, const int16_t *right_frames_host, long n_frames,
+                            double *corr4_inout_host)
+{
+    if (!h) return JDSP_EINVAL;
+    jdsp_ctx *ctx = h->ctx;
+    if (n_frames < 0 || n_frames > (1L << 28)) return fail(ctx, JDSP_EINVAL, "jdsp_mvdr_estimate_corr: n_frames");
+    if (n_frames == 0) return JDSP_OK;
+    if (!left_frames_host || !right_frames_host || !corr4_inout_host) return fail(ctx, JDSP_EINVAL, "jdsp_mvdr_estimate_corr: NULL buffer");
+    JDSP_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = mvdr_reserve(h, 2 * n_frames);
+    if (rc) return rc;
+    // frame i = blocks (2i, 2i+1) of a 2 n_frames-block stream; "event" i = block 2i+1 with its predecessor (:250-253)
+    std::vector<int> ev((size_t)n_frames);
+    for (long i = 0; i < n_frames; i++) ev[(size_t)i] = (int)(2 * i + 1);
+    const jdsp::DenoisePlan plan = {(int)n_frames, 0, 0, 0};
+    const size_t in_b = (size_t)n_frames * 2048;
+    int16_t *d_l = nullptr, *d_r = nullptr;
+    double *d_tot = nullptr;
+    hipStream_t s = ctx->stream;
+    hipError_t e = hipMalloc((void **)&d_l, in_b);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_r, in_b);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_tot, 4 * sizeof(double));
+    if (e == hipSuccess) e = hipMemcpyAsync(d_l, left_frames_host, in_b, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_r, right_frames_host, in_b, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(h->events, ev.data(), sizeof(int) * (size_t)n_frames, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(h->plan, &plan, sizeof(plan), hipMemcpyHostToDevice, s);
+    if (e != hipSuccess) rc = fail(ctx, JDSP_EHIP, "jdsp_mvdr_estimate_corr: staging", e);
+    double tot[4] = {0, 0, 0, 0};
+    if (!rc && jdsp::launch_mvdr_corr_total(s, d_l, d_r, 2 * n_frames, h->st[h->cur], h->events, h->plan, ctx->stft1024_table,
+                                            h->delta, d_tot))
+        rc = fail(ctx, JDSP_EHIP, "mvdr corr launch", hipGetLastError());
+    if (!rc && (e = hipMemcpyAsync(tot, d_tot, sizeof(tot), hipMemcpyDeviceToHost, s)) != hipSuccess)
+        rc = fail(ctx, JDSP_EHIP, "jdsp_mvdr_estimate_corr: D2H", e);
+    if ((e = hipStreamSynchronize(s)) != hipSuccess && !rc) rc = fail(ctx, JDSP_EHIP, "jdsp_mvdr_estimate_corr: sync", e);
+    if (d_l) (void)hipFree(d_l);
+    if (d_r) (void)hipFree(d_r);
+    if (d_tot) (void)hipFree(d_tot);
+    if (!rc)
+        for (int c = 0; c < 4; c++) corr4_inout_host[c] += tot[c];               // rgdSpatialCorr[..] += (:263-268)
+    return rc;
+}
+
+int jdsp_mvdr_apply(jdsp_mvdr *h, const int16_t *left_host, const int16_t *right_host, long n_blocks,
+                    const double *corr4_host, int16_t *out_host, float *precast_host, long *n_out_blocks)
+{
+    if (!h) return JDSP_EINVAL;
+    jdsp_ctx *ctx = h->ctx;
+    if (n_blocks < 0 || !corr4_host) return fail(ctx, JDSP_EINVAL, "jdsp_mvdr_apply: bad argument");
+    const long n_out = jdsp_mvdr_blocks_out(h, n_blocks);
+    if (n_out_blocks) *n_out_blocks = n_out;
+    if (n_blocks == 0) return JDSP_OK;
+    if (!left_host || !right_host || (n_out > 0 && !out_host)) return fail(ctx, JDSP_EINVAL, "jdsp_mvdr_apply: NULL buffer");
+    JDSP_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = mvdr_reserve(h, n_blocks);
+    if (rc) return rc;
+    const size_t in_b = (size_t)n_blocks * 1024, out_b = (size_t)(n_out > 0 ? n_out : 1) * 1024;
+    int16_t *d_l = nullptr, *d_r = nullptr, *d_out = nullptr;
+    float *d_pre = nullptr;
+    hipStream_t s = ctx->stream;
+    jdsp::MvdrState *st_in = h->st[h->cur], *st_out = h->st[h->cur ^ 1];
+    hipError_t e = hipMalloc((void **)&d_l, in_b);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_r, in_b);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_out, out_b);
+    if (e == hipSuccess && precast_host) e = hipMalloc((void **)&d_pre, out_b * 2);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_l, left_host, in_b, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_r, right_host, in_b, hipMemcpyHostToDevice, s);
+    // every block uses matrix version 0 = the caller's rgdSpatialCorr; the handle's own matrix and run length carry over
+    if (e == hipSuccess) e = hipMemcpyAsync(h->rver, corr4_host, 4 * sizeof(double), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemsetAsync(h->ver_base, 0, ((size_t)n_blocks / 64 + 1) * sizeof(int), s);
+    if (e == hipSuccess) e = hipMemsetAsync(h->snap_mask, 0, ((size_t)n_blocks / 64 + 1) * sizeof(unsigned long long), s);
+    if (e == hipSuccess) e = hipMemcpyAsync(st_out, st_in, sizeof(jdsp::MvdrState), hipMemcpyDeviceToDevice, s);
+    if (e != hipSuccess) rc = fail(ctx, JDSP_EHIP, "jdsp_mvdr_apply: staging", e);
+    if (!rc && jdsp::launch_mvdr_apply(s, d_l, d_r, n_blocks, h->calls, st_in, st_out, h->ver_base, h->snap_mask, h->rver,
+                                       h->steer, ctx->stft1024_table, d_out, d_pre))
+        rc = fail(ctx, JDSP_EHIP, "mvdr launch", hipGetLastError());
+    if (!rc && n_out > 0 && (e = hipMemcpyAsync(out_host, d_out, (size_t)n_out * 1024, hipMemcpyDeviceToHost, s)) != hipSuccess)
+        rc = fail(ctx, JDSP_EHIP, "jdsp_mvdr_apply: D2H", e);
+    if (!rc && n_out > 0 && precast_host &&
+        (e = hipMemcpyAsync(precast_host, d_pre, (size_t)n_out * 2048, hipMemcpyDeviceToHost, s)) != hipSuccess)
+        rc = fail(ctx, JDSP_EHIP, "jdsp_mvdr_apply: D2H", e);
+    if ((e = hipStreamSynchronize(s)) != hipSuccess && !rc) rc = fail(ctx, JDSP_EHIP, "jdsp_mvdr_apply: sync", e);
+    if (d_l) (void)hipFree(d_l);
+    if (d_r) (void)hipFree(d_r);
+    if (d_out) (void)hipFree(d_out);
+    if (d_pre) (void)hipFree(d_pre);
+    if (!rc) {
+        h->cur ^= 1;
+        h->calls += n_blocks;
+    }
+    return rc;
+}
+
 int jdsp_mvdr_corr(jdsp_mvdr *h, double *corr4_host)
 {
     if (!h || !corr4_host) return JDSP_EINVAL;

@@ -259,6 +259,36 @@ int launch_mvdr(hipStream_t s, const short *left, const short *right, long n_blo
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
+// EstimateSpatialCorrMtx on its own: the deltas of every listed event and their sum (no state touched).
+int launch_mvdr_corr_total(hipStream_t s, const short *left, const short *right, long n_blocks, const MvdrState *st_in,
+                           const int *events, const DenoisePlan *plan, const float2 *table, double *delta, double *total)
+{
+    if (n_blocks <= 0) return 0;
+    const long g1 = n_blocks < 2048 ? n_blocks : 2048;
+    hipLaunchKernelGGL(mvdr_corr_kernel, dim3((unsigned)g1), dim3(64), 0, s, left, right, n_blocks, st_in, events, plan,
+                       table, delta, (const int *)nullptr, 0L);
+    hipLaunchKernelGGL(mvdr_prefix_kernel, dim3(1), dim3(64), 0, s, delta, plan, (const int *)nullptr, (const double *)nullptr,
+                       (const double *)nullptr, 0, (MvdrState *)nullptr, (double *)nullptr, total);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// ProcessMVDR on its own: rver / ver_base / snap_mask are the caller's (jdsp_mvdr_apply: one matrix for every block).
+int launch_mvdr_apply(hipStream_t s, const short *left, const short *right, long n_blocks, long calls_before,
+                      const MvdrState *st_in, MvdrState *st_out, const int *ver_base, const unsigned long long *snap_mask,
+                      const double *rver, const double2 *steer, const float2 *table, short *out, float *precast)
+{
+    if (n_blocks <= 0) return 0;
+    DenoiseShard sh;
+    sh.ver_block_off = 0;
+    sh.ver_row_off = nullptr;
+    sh.emit_from = calls_before >= 1 ? 0 : 1;
+    sh.emit_to = n_blocks;
+    const long grid = (n_blocks + 7) / 8 * 8;
+    hipLaunchKernelGGL(mvdr_kernel, dim3((unsigned)grid), dim3(64), 0, s, left, right, n_blocks, calls_before, st_in,
+                       st_out, ver_base, snap_mask, rver, steer, table, out, precast, sh);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 // ---- sharded run (multi-GPU): see include/jdsp.h "sharded MVDR" --------------------------------
 __global__ void mvdr_event_range_kernel(const int *__restrict__ events, const DenoisePlan *__restrict__ plan,
                                         const int *__restrict__ ver_base,

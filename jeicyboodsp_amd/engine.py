@@ -120,6 +120,18 @@ class Engine:
                                        out.ctypes.data_as(C.c_void_p), n, x.size // n))
         return out
 
+    def gmm_probability(self, feats, mean, cov, eig):
+        """probability() (GMMAlgorithm_Test_Auto_ver2.cpp:164-236) of every 12-double vector of feats under one
+        mixture component (mean [12], cov [12, 12], eig [12, 4])."""
+        feats = np.ascontiguousarray(np.atleast_2d(feats), np.float64)
+        mean = np.ascontiguousarray(mean, np.float64)
+        cov = np.ascontiguousarray(cov, np.float64)
+        eig = np.ascontiguousarray(eig, np.float64)
+        assert feats.shape[1] == 12 and mean.size == 12 and cov.size == 144 and eig.size == 48
+        out = np.empty(feats.shape[0], np.float64)
+        self._ck(L.jdsp_gmm_probability(self._h, _vp(feats), feats.shape[0], _vp(mean), _vp(cov), _vp(eig), _vp(out)))
+        return out
+
     # ---- PitchEstimation_method1.cpp ---------------------------------------------
     def pitch(self, pcm, prev_block=None, want_autocorr=False):
         """CalcPitch (PitchEstimation_method1.cpp:69-116) for every 512-sample block of pcm:
@@ -348,6 +360,31 @@ class Mfcc:
 
     def n_frames(self, n_samples):
         return (n_samples - self.cfg.win_len) // self.cfg.hop + 1 if n_samples >= self.cfg.win_len else 0
+
+    # ---- the sub-steps on their own (MFCC:154-192), FP64, rows = independent frames
+    def mel_filterbank(self, mag):
+        """MelFilterBank: |X| [rows, n_fft/2] -> ln channel sums [rows, n_chan]."""
+        mag = np.ascontiguousarray(np.atleast_2d(mag), np.float64)
+        assert mag.shape[1] == self.cfg.n_fft // 2
+        out = np.empty((mag.shape[0], self.cfg.n_chan), np.float64)
+        self.eng._ck(L.jdsp_mfcc_melfilterbank(self._h, _vp(mag), mag.shape[0], _vp(out)))
+        return out
+
+    def dct(self, mel, accumulate_into=None):
+        """DCT: [rows, n_chan] -> [rows, n_cep], ADDED to accumulate_into (default zeros) like the reference."""
+        mel = np.ascontiguousarray(np.atleast_2d(mel), np.float64)
+        assert mel.shape[1] == self.cfg.n_chan
+        out = np.zeros((mel.shape[0], self.cfg.n_cep), np.float64) if accumulate_into is None else \
+            np.ascontiguousarray(np.atleast_2d(accumulate_into), np.float64).copy()
+        assert out.shape == (mel.shape[0], self.cfg.n_cep)
+        self.eng._ck(L.jdsp_mfcc_dct(self._h, _vp(mel), mel.shape[0], _vp(out)))
+        return out
+
+    def liftering(self, cep):
+        cep = np.ascontiguousarray(np.atleast_2d(cep), np.float64).copy()
+        assert cep.shape[1] == self.cfg.n_cep
+        self.eng._ck(L.jdsp_mfcc_liftering(self._h, _vp(cep), cep.shape[0]))
+        return cep
 
     def frames(self, pcm, n_frames=None, frame_start=None):
         """Feature vectors [n_frames, n_cep] float64; frame j starts at frame_start[j] (default hop*j)."""
@@ -594,6 +631,28 @@ class Mvdr:
         c = np.zeros(4, np.float64)
         self.eng._ck(L.jdsp_mvdr_corr(self._h, c.ctypes.data_as(C.c_void_p)))
         return c
+
+    def estimate_corr(self, left_frames, right_frames, corr):
+        """EstimateSpatialCorrMtx (BeamForming_MVDR_ver1.cpp:244-270): frames [n, 1024] per channel, returns
+        corr (4 doubles, row-major) + every frame's contribution."""
+        lf = np.ascontiguousarray(np.atleast_2d(left_frames), np.int16)
+        rf = np.ascontiguousarray(np.atleast_2d(right_frames), np.int16)
+        assert lf.shape == rf.shape and lf.shape[1] == 1024
+        c = np.ascontiguousarray(corr, np.float64).reshape(4).copy()
+        self.eng._ck(L.jdsp_mvdr_estimate_corr(self._h, _vp(lf), _vp(rf), lf.shape[0], _vp(c)))
+        return c
+
+    def apply(self, left, right, corr, want_precast=False):
+        """ProcessMVDR (:124-205) for whole blocks with the CALLER's matrix (4 doubles, row-major)."""
+        left = np.ascontiguousarray(left, np.int16)
+        right = np.ascontiguousarray(right, np.int16)
+        c = np.ascontiguousarray(corr, np.float64).reshape(4)
+        nb = left.size // 512
+        n_out = self.blocks_out(nb)
+        out = np.zeros(max(n_out, 1) * 512, np.int16)
+        pre = np.zeros(max(n_out, 1) * 512, np.float32) if want_precast else None
+        self.eng._ck(L.jdsp_mvdr_apply(self._h, _vp(left), _vp(right), nb, _vp(c), _vp(out), _vp(pre), None))
+        return (out[:n_out * 512], pre[:n_out * 512]) if want_precast else out[:n_out * 512]
 
     # ---- one rank's share of a global stream (jdsp_mvdr_shard_*)
     def shard_vad(self, left_ext, right_ext, ext0, b0, b1, n_total):

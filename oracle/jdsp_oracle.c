@@ -437,6 +437,40 @@ void orc_mel_init(const orc_mfcc_cfg *c, double *mel, int *fi, double *fb)
     }
 }
 
+/* :154-174 MelFilterBank: triangular weighting in bin order, then ln */
+void orc_mel_filterbank(const orc_mfcc_cfg *c, const int *fi, const double *fb, const double *mag, double *mel)
+{
+    const int C = c->n_chan;
+    double *m = (double *)calloc((size_t)C, sizeof(double));               /* rgdMelFiltered = {0} (:156) */
+    for (int i = 0; i < c->n_bins; i++) {                                  /* :157-168 */
+        int k = fi[i];
+        if (k == 0) {
+            m[k] += (1 - fb[i]) * mag[i];
+        } else {
+            m[k - 1] += fb[i] * mag[i];
+            if (k != C) m[k] += (1 - fb[i]) * mag[i];
+        }
+    }
+    for (int i = 0; i < C; i++) mel[i] = log(m[i]);                        /* :170-172 */
+    free(m);
+}
+
+/* :176-183 DCT: ACCUMULATES into cep (the caller zeroes it, :224) */
+void orc_dct(const orc_mfcc_cfg *c, const double *mel, double *cep)
+{
+    const int C = c->n_chan;
+    for (int i = 1; i <= c->n_cep; i++)
+        for (int k = 1; k <= C; k++)
+            cep[i - 1] += sqrt(2.0 / C) * mel[k - 1] * cos(PI_APPS * i * (k - 0.5) / (double)C);
+}
+
+/* :185-192 Liftering, in place */
+void orc_liftering(const orc_mfcc_cfg *c, double *cep)
+{
+    for (int i = 1; i <= c->n_cep; i++)
+        cep[i - 1] = cep[i - 1] * (1 + 0.5 * c->lifter * sin(PI_APPS * i / c->lifter));
+}
+
 void orc_mfcc_frame(const orc_mfcc_cfg *c, const int *fi, const double *fb,
                     const short *frame, double *cep)
 {
@@ -452,22 +486,10 @@ void orc_mfcc_frame(const orc_mfcc_cfg *c, const int *fi, const double *fb,
     orc_dft_c2c(x, X, N, -1);                                              /* :216-217 */
     for (int i = 0; i < N; i++)                                            /* :218-220 */
         mag[i] = sqrt(pow(X[i].re, 2) + pow(X[i].im, 2));
-    for (int i = 0; i < c->n_bins; i++) {                                  /* :157-168 */
-        int k = fi[i];
-        if (k == 0) {
-            m[k] += (1 - fb[i]) * mag[i];
-        } else {
-            m[k - 1] += fb[i] * mag[i];
-            if (k != C) m[k] += (1 - fb[i]) * mag[i];
-        }
-    }
-    for (int i = 0; i < C; i++) m[i] = log(m[i]);                          /* :170-172 */
-    for (int i = 1; i <= c->n_cep; i++) {                                  /* :178-182 */
-        double acc = 0.0;
-        for (int k = 1; k <= C; k++)
-            acc += sqrt(2.0 / C) * m[k - 1] * cos(PI_APPS * i * (k - 0.5) / (double)C);
-        cep[i - 1] = acc * (1 + 0.5 * c->lifter * sin(PI_APPS * i / c->lifter));   /* :189 */
-    }
+    orc_mel_filterbank(c, fi, fb, mag, m);                                 /* :223 */
+    for (int i = 0; i < c->n_cep; i++) cep[i] = 0.0;                       /* :224 memset */
+    orc_dct(c, m, cep);                                                    /* :225 */
+    orc_liftering(c, cep);                                                 /* :226 */
     free(x); free(X); free(mag); free(m);
 }
 
@@ -543,16 +565,87 @@ static int mvdr_vad(const short *block)
     return e > 700.0;                                                                       /* :233 */
 }
 
-long orc_mvdr_stream(const short *left, const short *right, long n_blocks, double d_time,
-                     short *out, double *pre_cast, double *corr4, double *corr_trace)
+/* EstimateSpatialCorrMtx :244-270: one [previous block, block] frame per channel, ADDED to R (row-major) */
+void orc_mvdr_estimate(const short *temp_l, const short *temp_r, double *R4)
+{
+    orc_cplx *fl = (orc_cplx *)calloc(MV_N, sizeof(orc_cplx)), *FL = (orc_cplx *)calloc(MV_N, sizeof(orc_cplx));
+    orc_cplx *fr = (orc_cplx *)calloc(MV_N, sizeof(orc_cplx)), *FR = (orc_cplx *)calloc(MV_N, sizeof(orc_cplx));
+    for (int i = 0; i < MV_N; i++) { fl[i].re = temp_l[i]; fl[i].im = 0; fr[i].re = temp_r[i]; fr[i].im = 0; }
+    orc_dft_c2c(fl, FL, MV_N, -1);
+    orc_dft_c2c(fr, FR, MV_N, -1);
+    for (int i = 0; i < MV_N; i++) {                                                     /* :263-268 */
+        R4[0] += (pow(FL[i].re, 2.0) + pow(FL[i].im, 2.0)) / MV_N;
+        R4[1] += (-FL[i].re * FR[i].im + FL[i].im * FR[i].re) / MV_N;
+        R4[2] += (-FR[i].re * FL[i].im + FR[i].im * FL[i].re) / MV_N;
+        R4[3] += (pow(FR[i].re, 2.0) + pow(FR[i].im, 2.0)) / MV_N;
+    }
+    free(fl); free(FL); free(fr); free(FR);
+}
+
+/* ProcessMVDR's statics (:130-131,:137) */
+struct orc_mvdr {
+    double keep_l[MV_KEEP], keep_r[MV_KEEP];
+    int count;
+};
+orc_mvdr *orc_mvdr_create(void) { return (orc_mvdr *)calloc(1, sizeof(orc_mvdr)); }
+void orc_mvdr_destroy(orc_mvdr *s) { free(s); }
+
+/* ProcessMVDR :124-205 for one block with the CALLER's matrix R4 (row-major).  Returns 1 when the reference
+ * returns true (from the second call on); out / pre_cast are written on every call like the reference's
+ * rgsOutputBuffer. */
+int orc_mvdr_process_block(orc_mvdr *st, const short *L, const short *Rr, double d_time, const double *R4,
+                           short *out, double *pre_cast)
 {
     orc_cplx *fl = (orc_cplx *)calloc(MV_N, sizeof(orc_cplx)), *FL = (orc_cplx *)calloc(MV_N, sizeof(orc_cplx));
     orc_cplx *fr = (orc_cplx *)calloc(MV_N, sizeof(orc_cplx)), *FR = (orc_cplx *)calloc(MV_N, sizeof(orc_cplx));
     orc_cplx *mg = (orc_cplx *)calloc(MV_N, sizeof(orc_cplx)), *MG = (orc_cplx *)calloc(MV_N, sizeof(orc_cplx));
-    double keep_l[MV_KEEP] = {0}, keep_r[MV_KEEP] = {0};               /* :259-261 */
+    st->count++;
+    for (int i = 0; i < MV_KEEP; i++) { fl[i].re = st->keep_l[i]; fr[i].re = st->keep_r[i]; }       /* :136-137 */
+    for (int i = 0; i < MV_BLOCK; i++) { fl[i + MV_KEEP].re = L[i]; fr[i + MV_KEEP].re = Rr[i]; }   /* :138-141 */
+    orc_dft_c2c(fl, FL, MV_N, -1);
+    orc_dft_c2c(fr, FR, MV_N, -1);
+    {
+        /* mxAutoCorr.inverse() for a 2x2: adjugate times 1/det (complex scalars, zero imaginary parts) */
+        double complex a = R4[0], bb = R4[1], c = R4[2], d = R4[3];
+        double complex invdet = 1.0 / (a * d - bb * c);
+        double complex i00 = d * invdet, i01 = -bb * invdet, i10 = -c * invdet, i11 = a * invdet;
+        for (int i = 0; i < MV_N; i++) {
+            double ang = 2 * PI_APPS * i * (16000.0 / MV_N) * d_time;                /* :164-165 */
+            double complex s0 = 1.0, s1 = cos(ang) + I * sin(ang);
+            double complex w0 = i00 * s0 + i01 * s1, w1 = i10 * s0 + i11 * s1;       /* :170 */
+            double complex den = conj(s0) * w0 + conj(s1) * w1;                      /* :171 */
+            w0 /= den;
+            w1 /= den;
+            double lw0 = creal(w0), lw1 = -cimag(w0), rw0 = creal(w1), rw1 = -cimag(w1);   /* :175-178 */
+            /* :180-183 -- the imaginary part uses the ALREADY OVERWRITTEN real part */
+            FL[i].re = FL[i].re * lw0 - FL[i].im * lw1;
+            FL[i].im = FL[i].re * lw1 + FL[i].im * lw0;
+            FR[i].re = FR[i].re * rw0 - FR[i].im * rw1;
+            FR[i].im = FR[i].re * rw1 + FR[i].im * rw0;
+            mg[i].re = FL[i].re + FR[i].re;                                          /* :184-185 */
+            mg[i].im = FL[i].im + FR[i].im;
+        }
+    }
+    orc_dft_c2c(mg, MG, MV_N, +1);                                                   /* :189-190 */
+    for (int i = 0; i < MV_BLOCK; i++) {
+        double v = MG[i + MV_KEEP].re * 1. / MV_N;                                   /* :193 */
+        if (out) out[i] = cast_i16(v);
+        if (pre_cast) pre_cast[i] = v;
+    }
+    for (int i = 0; i < MV_KEEP; i++) { st->keep_l[i] = fl[MV_KEEP + i].re; st->keep_r[i] = fr[MV_KEEP + i].re; }   /* :195-196 */
+    free(fl); free(FL); free(fr); free(FR); free(mg); free(MG);
+    return st->count > 1;                                                            /* :201-204 */
+}
+
+long orc_mvdr_stream(const short *left, const short *right, long n_blocks, double d_time,
+                     short *out, double *pre_cast, double *corr4, double *corr_trace)
+{
     short temp_l[2 * MV_BLOCK] = {0}, temp_r[2 * MV_BLOCK] = {0};      /* :111 */
-    double R[2][2] = {{0, 0}, {0, 0}};                                  /* :113 */
-    int iter = 0, count = 0;
+    double R[4] = {0, 0, 0, 0};                                         /* :113 */
+    short ob[MV_BLOCK];
+    double pb[MV_BLOCK];
+    orc_mvdr *st = orc_mvdr_create();
+    int iter = 0;
     long n_out = 0;
     for (long b = 0; b < n_blocks; b++) {
         const short *L = left + (size_t)b * MV_BLOCK, *Rr = right + (size_t)b * MV_BLOCK;
@@ -561,66 +654,22 @@ long orc_mvdr_stream(const short *left, const short *right, long n_blocks, doubl
             if (iter > 1) {
                 memcpy(temp_l + MV_BLOCK, L, sizeof(short) * MV_BLOCK);
                 memcpy(temp_r + MV_BLOCK, Rr, sizeof(short) * MV_BLOCK);
-                /* EstimateSpatialCorrMtx :244-270 */
-                for (int i = 0; i < MV_N; i++) { fl[i].re = temp_l[i]; fl[i].im = 0; fr[i].re = temp_r[i]; fr[i].im = 0; }
-                orc_dft_c2c(fl, FL, MV_N, -1);
-                orc_dft_c2c(fr, FR, MV_N, -1);
-                for (int i = 0; i < MV_N; i++) {
-                    R[0][0] += (pow(FL[i].re, 2.0) + pow(FL[i].im, 2.0)) / MV_N;
-                    R[0][1] += (-FL[i].re * FR[i].im + FL[i].im * FR[i].re) / MV_N;
-                    R[1][0] += (-FR[i].re * FL[i].im + FR[i].im * FL[i].re) / MV_N;
-                    R[1][1] += (pow(FR[i].re, 2.0) + pow(FR[i].im, 2.0)) / MV_N;
-                }
+                orc_mvdr_estimate(temp_l, temp_r, R);
             }
             memcpy(temp_l, L, sizeof(short) * MV_BLOCK);
             memcpy(temp_r, Rr, sizeof(short) * MV_BLOCK);
         } else {
             iter = 0;
         }
-        if (corr_trace) { corr_trace[4 * b] = R[0][0]; corr_trace[4 * b + 1] = R[0][1]; corr_trace[4 * b + 2] = R[1][0]; corr_trace[4 * b + 3] = R[1][1]; }
-        /* ProcessMVDR :124-205 */
-        count++;
-        memset(fl, 0, sizeof(orc_cplx) * MV_N);
-        memset(fr, 0, sizeof(orc_cplx) * MV_N);
-        for (int i = 0; i < MV_KEEP; i++) { fl[i].re = keep_l[i]; fr[i].re = keep_r[i]; }               /* :136-137 */
-        for (int i = 0; i < MV_BLOCK; i++) { fl[i + MV_KEEP].re = L[i]; fr[i + MV_KEEP].re = Rr[i]; }   /* :138-141 */
-        orc_dft_c2c(fl, FL, MV_N, -1);
-        orc_dft_c2c(fr, FR, MV_N, -1);
-        {
-            /* mxAutoCorr.inverse() for a 2x2: adjugate times 1/det (complex scalars, zero imaginary parts) */
-            double complex a = R[0][0], bb = R[0][1], c = R[1][0], d = R[1][1];
-            double complex invdet = 1.0 / (a * d - bb * c);
-            double complex i00 = d * invdet, i01 = -bb * invdet, i10 = -c * invdet, i11 = a * invdet;
-            for (int i = 0; i < MV_N; i++) {
-                double ang = 2 * PI_APPS * i * (16000.0 / MV_N) * d_time;                /* :164-165 */
-                double complex s0 = 1.0, s1 = cos(ang) + I * sin(ang);
-                double complex w0 = i00 * s0 + i01 * s1, w1 = i10 * s0 + i11 * s1;       /* :170 */
-                double complex den = conj(s0) * w0 + conj(s1) * w1;                      /* :171 */
-                w0 /= den;
-                w1 /= den;
-                double lw0 = creal(w0), lw1 = -cimag(w0), rw0 = creal(w1), rw1 = -cimag(w1);   /* :175-178 */
-                /* :180-183 -- the imaginary part uses the ALREADY OVERWRITTEN real part */
-                FL[i].re = FL[i].re * lw0 - FL[i].im * lw1;
-                FL[i].im = FL[i].re * lw1 + FL[i].im * lw0;
-                FR[i].re = FR[i].re * rw0 - FR[i].im * rw1;
-                FR[i].im = FR[i].re * rw1 + FR[i].im * rw0;
-                mg[i].re = FL[i].re + FR[i].re;                                          /* :184-185 */
-                mg[i].im = FL[i].im + FR[i].im;
-            }
-        }
-        orc_dft_c2c(mg, MG, MV_N, +1);                                                   /* :189-190 */
-        if (count > 1) {                                                                 /* :201-204 */
-            for (int i = 0; i < MV_BLOCK; i++) {
-                double v = MG[i + MV_KEEP].re * 1. / MV_N;                               /* :193 */
-                out[(size_t)n_out * MV_BLOCK + i] = cast_i16(v);
-                if (pre_cast) pre_cast[(size_t)n_out * MV_BLOCK + i] = v;
-            }
+        if (corr_trace) memcpy(corr_trace + 4 * b, R, sizeof(R));
+        if (orc_mvdr_process_block(st, L, Rr, d_time, R, ob, pb)) {
+            memcpy(out + (size_t)n_out * MV_BLOCK, ob, sizeof(ob));
+            if (pre_cast) memcpy(pre_cast + (size_t)n_out * MV_BLOCK, pb, sizeof(pb));
             n_out++;
         }
-        for (int i = 0; i < MV_KEEP; i++) { keep_l[i] = fl[MV_KEEP + i].re; keep_r[i] = fr[MV_KEEP + i].re; }   /* :195-196 */
     }
-    if (corr4) { corr4[0] = R[0][0]; corr4[1] = R[0][1]; corr4[2] = R[1][0]; corr4[3] = R[1][1]; }
-    free(fl); free(FL); free(fr); free(FR); free(mg); free(MG);
+    if (corr4) memcpy(corr4, R, sizeof(R));
+    orc_mvdr_destroy(st);
     return n_out;
 }
 

@@ -96,6 +96,11 @@ typedef struct {
 void orc_mfcc_native_cfg(orc_mfcc_cfg *c);
 /* :118-152 MelFilterBankInit: mel_freqs[n_chan+1], fi_bins[n_bins], fbank[n_bins] */
 void orc_mel_init(const orc_mfcc_cfg *c, double *mel_freqs, int *fi_bins, double *fbank);
+/* :154-174 MelFilterBank(dAbs, dMelFiltered): mag[n_bins] -> ln of the n_chan channel sums.
+ * :176-183 DCT(dMelFiltered, dMFCCFeature): ACCUMULATES into cep[n_cep].  :185-192 Liftering(cep), in place. */
+void orc_mel_filterbank(const orc_mfcc_cfg *c, const int *fi_bins, const double *fbank, const double *mag, double *mel);
+void orc_dct(const orc_mfcc_cfg *c, const double *mel, double *cep);
+void orc_liftering(const orc_mfcc_cfg *c, double *cep);
 /* :194-231 per frame: frame = win_len int16 samples -> n_cep doubles.
  * x[0] stays 0 (:208 starts at i=1). */
 void orc_mfcc_frame(const orc_mfcc_cfg *c, const int *fi_bins, const double *fbank,
@@ -120,6 +125,16 @@ void orc_pitch_stream(const short *pcm, long n_blocks, int *arg, double *rmax, d
  * invertible the reference's output is NaN; (short)NaN is 0 here as everywhere. */
 long orc_mvdr_stream(const short *left, const short *right, long n_blocks, double d_time,
                      short *out, double *pre_cast, double *corr4, double *corr_trace);
+/* The same program function by function, for callers that do not follow main()'s protocol:
+ * EstimateSpatialCorrMtx (:244-270) on one 1024-sample [previous block, block] frame per channel, ADDED to R4
+ * (row-major rgdSpatialCorr); ProcessMVDR (:124-205) for one block with the caller's R4 (its statics -- the two
+ * 511-sample keep buffers and the call counter -- live in orc_mvdr).  Returns 1 from the second call on. */
+typedef struct orc_mvdr orc_mvdr;
+void orc_mvdr_estimate(const short *temp_l, const short *temp_r, double *R4);
+orc_mvdr *orc_mvdr_create(void);
+void orc_mvdr_destroy(orc_mvdr *s);
+int orc_mvdr_process_block(orc_mvdr *st, const short *left, const short *right, double d_time, const double *R4,
+                           short *out, double *pre_cast);
 
 /* BASELINE config 5 / SURVEY §8f rank 3: the MVDR beamformer generalised to n_mics <= 8 microphones
  * with a PER-BIN n_mics x n_mics covariance.  NOT what the reference computes (it has 2 mics and

@@ -73,6 +73,12 @@ class Oracle:
         L.orc_mvdr_stream.argtypes = [_c_short_p, _c_short_p, C.c_long, C.c_double, _c_short_p, _c_double_p,
                                       _c_double_p, _c_double_p]
         L.orc_mvdr_stream.restype = C.c_long
+        L.orc_mvdr_estimate.argtypes = [_c_short_p, _c_short_p, _c_double_p]
+        L.orc_mvdr_create.restype = C.c_void_p
+        L.orc_mvdr_destroy.argtypes = [C.c_void_p]
+        L.orc_mvdr_process_block.argtypes = [C.c_void_p, _c_short_p, _c_short_p, C.c_double, _c_double_p, _c_short_p,
+                                             _c_double_p]
+        L.orc_mvdr_process_block.restype = C.c_int
         L.orc_mvdrn_stream.argtypes = [_c_short_p, C.c_long, C.c_int, C.c_long, _c_double_p, C.c_double, _c_short_p,
                                        _c_double_p]
         L.orc_mvdrn_stream.restype = C.c_long
@@ -86,6 +92,9 @@ class Oracle:
         L.orc_hmm_viterbi.restype = C.c_double
         L.orc_mfcc_native_cfg.argtypes = [C.POINTER(MfccCfg)]
         L.orc_mel_init.argtypes = [C.POINTER(MfccCfg), _c_double_p, _c_int_p, _c_double_p]
+        L.orc_mel_filterbank.argtypes = [C.POINTER(MfccCfg), _c_int_p, _c_double_p, _c_double_p, _c_double_p]
+        L.orc_dct.argtypes = [C.POINTER(MfccCfg), _c_double_p, _c_double_p]
+        L.orc_liftering.argtypes = [C.POINTER(MfccCfg), _c_double_p]
         L.orc_mfcc_frame.argtypes = [C.POINTER(MfccCfg), _c_int_p, _c_double_p, _c_short_p, _c_double_p]
         L.orc_mfcc_stream.argtypes = [C.POINTER(MfccCfg), _c_short_p, C.c_long, _c_double_p]
         L.orc_mfcc_stream.restype = C.c_long
@@ -249,6 +258,34 @@ class Oracle:
                                      _p(pre, _c_double_p), _p(corr, _c_double_p), _p(trace, _c_double_p))
         return out[:n * 512].copy(), pre[:n * 512].copy(), corr, trace[:nb]
 
+    def mvdr_estimate(self, temp_l, temp_r, corr):
+        """EstimateSpatialCorrMtx on one 1024-sample frame per channel: returns corr + the frame's contribution."""
+        tl = np.ascontiguousarray(temp_l, np.int16)
+        tr = np.ascontiguousarray(temp_r, np.int16)
+        assert tl.size == 1024 and tr.size == 1024
+        c = np.ascontiguousarray(corr, np.float64).reshape(4).copy()
+        self.lib.orc_mvdr_estimate(_p(tl, _c_short_p), _p(tr, _c_short_p), _p(c, _c_double_p))
+        return c
+
+    def mvdr_apply(self, left, right, corr, d_time=0.0):
+        """ProcessMVDR block by block with ONE caller matrix: (int16 out, pre-cast) of the blocks it returns true for."""
+        left = np.ascontiguousarray(left, np.int16)
+        right = np.ascontiguousarray(right, np.int16)
+        c = np.ascontiguousarray(corr, np.float64).reshape(4)
+        st = self.lib.orc_mvdr_create()
+        outs, pres = [], []
+        ob, pb = np.zeros(512, np.int16), np.zeros(512, np.float64)
+        for b in range(left.size // 512):
+            ok = self.lib.orc_mvdr_process_block(st, _p(left[b * 512:(b + 1) * 512].copy(), _c_short_p),
+                                                 _p(right[b * 512:(b + 1) * 512].copy(), _c_short_p), d_time,
+                                                 _p(c, _c_double_p), _p(ob, _c_short_p), _p(pb, _c_double_p))
+            if ok:
+                outs.append(ob.copy())
+                pres.append(pb.copy())
+        self.lib.orc_mvdr_destroy(st)
+        cat = lambda l, dt: np.concatenate(l) if l else np.zeros(0, dt)
+        return cat(outs, np.int16), cat(pres, np.float64)
+
     def mvdrn_stream(self, pcm, delays=None, loading=0.0):
         """pcm: int16 [n_mics, n_samples] (planar)."""
         pcm = np.ascontiguousarray(pcm, np.int16)
@@ -278,6 +315,30 @@ class Oracle:
         fb = np.zeros(cfg.n_bins, np.float64)
         self.lib.orc_mel_init(C.byref(cfg), _p(mel, _c_double_p), _p(fi, _c_int_p), _p(fb, _c_double_p))
         return mel, fi, fb
+
+    def mel_filterbank(self, cfg, mag):
+        """MelFilterBank (MFCC:154-174) per row of |X| [rows, n_bins] -> [rows, n_chan]."""
+        mag = np.ascontiguousarray(np.atleast_2d(mag), np.float64)
+        _, fi, fb = self.mel_init(cfg)
+        out = np.zeros((mag.shape[0], cfg.n_chan), np.float64)
+        for r in range(mag.shape[0]):
+            self.lib.orc_mel_filterbank(C.byref(cfg), _p(fi, _c_int_p), _p(fb, _c_double_p), _p(mag[r], _c_double_p),
+                                        _p(out[r], _c_double_p))
+        return out
+
+    def dct(self, cfg, mel, accumulate_into=None):
+        mel = np.ascontiguousarray(np.atleast_2d(mel), np.float64)
+        out = np.zeros((mel.shape[0], cfg.n_cep), np.float64) if accumulate_into is None else \
+            np.ascontiguousarray(np.atleast_2d(accumulate_into), np.float64).copy()
+        for r in range(mel.shape[0]):
+            self.lib.orc_dct(C.byref(cfg), _p(mel[r], _c_double_p), _p(out[r], _c_double_p))
+        return out
+
+    def liftering(self, cfg, cep):
+        cep = np.ascontiguousarray(np.atleast_2d(cep), np.float64).copy()
+        for r in range(cep.shape[0]):
+            self.lib.orc_liftering(C.byref(cfg), _p(cep[r], _c_double_p))
+        return cep
 
     def mfcc_frames(self, cfg, pcm, n_frames, first_frame=0):
         """frame j = pcm[hop*(first_frame+j) : +win_len]"""

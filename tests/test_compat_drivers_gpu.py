@@ -340,3 +340,71 @@ def test_compat_mvdr_per_block_functions(tmp_path, oracle):
     assert got.shape == want.shape == ((n_blocks - 1) * 512,)
     assert np.abs(got.astype(np.int32) - want.astype(np.int32)).max() <= 1
     assert np.abs(corr - o_corr).max() <= 1e-5 * np.abs(o_corr).max()
+
+
+def test_compat_mvdr_functions_out_of_order(tmp_path, oracle):
+    """ProcessMVDR with a caller-set matrix before any estimate, EstimateSpatialCorrMtx on arbitrary frames into a
+    pre-filled matrix, ProcessMVDR again with the result (compat_mvdr_selftest ... ooo): each function must do its
+    own job whatever the call order (BeamForming_MVDR_ver1.cpp:124-205, :244-270)."""
+    if not os.path.exists(os.path.join(COMPAT, "compat_mvdr_selftest")):
+        subprocess.check_call(["make", "-s", "-C", COMPAT])
+    rng = np.random.default_rng(95)
+    left = speechlike(96, 8)
+    right = np.clip(np.rint(0.6 * np.roll(left, 3).astype(np.float64) + rng.normal(0, 200, left.size)), -32768, 32767).astype(np.int16)
+    left.tofile(tmp_path / "l.raw")
+    right.tofile(tmp_path / "r.raw")
+    run("compat_mvdr_selftest", tmp_path / "l.raw", tmp_path / "r.raw", tmp_path / "out.bin", "ooo")
+    raw = np.fromfile(tmp_path / "out.bin", np.uint8)
+    got = raw[:-32].view(np.int16)
+    corr = raw[-32:].view(np.float64)
+    blk = lambda x, b: x[b * 512:(b + 1) * 512]
+    c0 = np.array([4.0e6, 1.5e5, -2.5e5, 3.0e6])
+    c1 = c0
+    for a, b in ((3, 4), (7, 5)):
+        c1 = oracle.mvdr_estimate(np.concatenate([blk(left, a), blk(left, b)]), np.concatenate([blk(right, a), blk(right, b)]), c1)
+    assert np.abs(corr - c1).max() <= 1e-5 * np.abs(c1).max()
+    # one ProcessMVDR stream of blocks 0..5: matrix c0 for blocks 0..2, c1 for 3..5 (the keep buffers run through)
+    st = oracle.lib.orc_mvdr_create()
+    import ctypes as C
+    want = []
+    ob = np.zeros(512, np.int16)
+    for b in range(6):
+        c = np.ascontiguousarray(c0 if b < 3 else c1)
+        ok = oracle.lib.orc_mvdr_process_block(st, blk(left, b).copy().ctypes.data_as(C.POINTER(C.c_short)),
+                                               blk(right, b).copy().ctypes.data_as(C.POINTER(C.c_short)), 0.0,
+                                               c.ctypes.data_as(C.POINTER(C.c_double)),
+                                               ob.ctypes.data_as(C.POINTER(C.c_short)), None)
+        if ok:
+            want.append(ob.copy())
+    oracle.lib.orc_mvdr_destroy(st)
+    want = np.concatenate(want)
+    assert got.shape == want.shape == (5 * 512,)
+    assert np.abs(got.astype(np.int32) - want.astype(np.int32)).max() <= 1
+
+
+def test_compat_mfcc_sub_steps_and_probability(tmp_path, oracle):
+    """MelFilterBank / DCT / Liftering (MFCCFeatureExtraction_auto_version1.cpp:40-42,:154-192) and probability()
+    (GMMAlgorithm_Test_Auto_ver2.cpp:43,:164) with the reference's own signatures, one row / one vector per call."""
+    import gmm_cases
+    rng = np.random.default_rng(97)
+    mag = np.abs(rng.normal(0, 4e4, (6, 512))) + 1.0
+    mag.tofile(tmp_path / "abs.f64")
+    run("compat_selftest", "mfccsteps", tmp_path / "abs.f64", tmp_path / "steps.bin")
+    got = np.fromfile(tmp_path / "steps.bin", np.float64).reshape(6, 38 + 12 + 12)
+    cfg = oracle.mfcc_native_cfg()
+    mel = oracle.mel_filterbank(cfg, mag)
+    feat = oracle.liftering(cfg, oracle.dct(cfg, mel))
+    pre = oracle.dct(cfg, mel, accumulate_into=np.tile(100.0 + np.arange(12), (6, 1)))
+    assert np.abs(got[:, :38] - mel).max() <= 1e-12 * np.abs(mel).max()
+    assert np.abs(got[:, 38:50] - feat).max() <= 1e-11 * np.abs(feat).max()
+    assert np.abs(got[:, 50:] - pre).max() <= 1e-11 * np.abs(pre).max()
+    rec = gmm_cases.gmm_records(8, 1)
+    vec = gmm_cases.vectors(9, 50)
+    vec.tofile(tmp_path / "v.mfc")
+    rec.tofile(tmp_path / "g.bin")
+    run("compat_selftest", "prob", tmp_path / "v.mfc", tmp_path / "p.bin", tmp_path / "g.bin")
+    p = np.fromfile(tmp_path / "p.bin", np.float64).reshape(50, 4)
+    want = np.array([[oracle.gmm_probability(v, rec[0]["mean"][k], rec[0]["covariance"][k], rec[0]["eigenVector"][k])
+                      for k in range(4)] for v in vec])
+    ok = want > 0
+    assert np.abs(p[ok] / want[ok] - 1).max() < 1e-10 and np.array_equal(p == 0, want == 0)

@@ -253,3 +253,18 @@ def test_gmm_hmm_errors(eng):
     with pytest.raises(jeicyboodsp_amd.JdspError):
         h.viterbi(gc.vectors(1, 10), np.array([2, 10], np.int64))     # host table must start at 0
     h.close()
+
+
+def test_probability_on_its_own_matches_the_oracle(eng, oracle):
+    """probability() (GMMAlgorithm_Test_Auto_ver2.cpp:43,:164-236) as a separately callable entry: every vector
+    under every mixture component of a record, against the oracle's restatement (1e-12: exp's last place)."""
+    import gmm_cases
+    rec = gmm_cases.gmm_records(5, 1)[0]
+    vec = gmm_cases.vectors(6, 200)
+    for k in range(4):
+        got = eng.gmm_probability(vec, rec["mean"][k], rec["covariance"][k], rec["eigenVector"][k])
+        want = np.array([oracle.gmm_probability(v, rec["mean"][k], rec["covariance"][k], rec["eigenVector"][k]) for v in vec])
+        assert np.array_equal(np.isfinite(got), np.isfinite(want))
+        ok = np.isfinite(want) & (want != 0)
+        assert np.abs(got[ok] - want[ok]).max() <= 1e-12 * np.abs(want[ok]).max()
+        assert (np.abs(got[ok] / want[ok] - 1) < 1e-10).all()

@@ -171,3 +171,47 @@ def test_baseline_config4_ten_thousand_ragged_utterances(eng, oracle):
     alone = m.frames(pcm[offs[u]:offs[u + 1]])
     assert np.array_equal(alone, feats[first[u]:first[u + 1]].cpu().numpy())
     m.close()
+
+
+# ---- MelFilterBank / DCT / Liftering as functions of their own (MFCC:154-192) ----------------------
+STEP_TOL = 1e-12          # FP64 in the reference's order; only log() can differ from the CPU, in its last place
+
+
+@pytest.mark.parametrize("kw,n_bins", [(dict(), 512), (dict(win_len=400, hop=160, n_fft=512, n_chan=40, n_cep=13, half_rate=8000.0), 256)])
+def test_mfcc_sub_steps_match_the_oracle(eng, oracle, kw, n_bins):
+    ocfg = oracle.mfcc_cfg(n_bins=n_bins, **kw)
+    m = eng.mfcc(**kw)
+    rng = np.random.default_rng(9)
+    mag = np.abs(rng.normal(0, 5e4, (37, n_bins))) + 1.0
+    mel = m.mel_filterbank(mag)
+    want_mel = oracle.mel_filterbank(ocfg, mag)
+    assert mel.shape == want_mel.shape and np.abs(mel - want_mel).max() <= STEP_TOL * np.abs(want_mel).max()
+    cep = m.dct(want_mel)
+    want_cep = oracle.dct(ocfg, want_mel)
+    assert np.abs(cep - want_cep).max() <= STEP_TOL * np.abs(want_cep).max()
+    # the reference's DCT accumulates (:180 `+=`): a pre-filled output comes back as pre-fill + DCT
+    pre = rng.normal(0, 100, want_cep.shape)
+    acc = m.dct(want_mel, accumulate_into=pre)
+    assert np.abs(acc - oracle.dct(ocfg, want_mel, accumulate_into=pre)).max() <= STEP_TOL * np.abs(pre).max()
+    assert np.abs(acc - cep).max() > 1.0
+    lif = m.liftering(want_cep)
+    assert np.array_equal(lif, oracle.liftering(ocfg, want_cep))            # one multiply by a host-built constant
+    # chained, the three steps are MFCCFeatureExtraction's tail (:223-226): equal to the fused kernel's vectors
+    pcm = _pcm(21, m.cfg.win_len + m.cfg.hop * 4)
+    fused = m.frames(pcm)
+    spec_n = m.cfg.n_fft
+    frames = np.stack([pcm[m.cfg.hop * j:m.cfg.hop * j + m.cfg.win_len].astype(np.float64) for j in range(5)])
+    x = np.zeros((5, spec_n))
+    x[:, 1:m.cfg.win_len] = frames[:, 1:] - m.cfg.preemph * frames[:, :-1]
+    x[:, :m.cfg.win_len] *= oracle.hamming(m.cfg.win_len)
+    mag2 = np.abs(np.fft.fft(x, axis=1))[:, :n_bins]
+    chained = m.liftering(m.dct(m.mel_filterbank(mag2)))
+    _check(fused, chained)
+    m.close()
+
+
+def test_mel_filterbank_empty_channel_gives_minus_inf(eng, oracle):
+    m = eng.mfcc()
+    mel = m.mel_filterbank(np.zeros((1, 512)))
+    assert np.all(np.isneginf(mel))                                         # ln(0), as the reference (:171)
+    m.close()

@@ -122,3 +122,34 @@ def test_mvdr_sharded_equals_single(eng, oracle, world):
         k["m"].close()
     assert got.shape == o_out.shape
     assert np.abs(got.astype(np.int32) - o_out.astype(np.int32)).max() <= 1
+
+
+def test_estimate_and_apply_on_their_own_in_any_order(eng, oracle):
+    """EstimateSpatialCorrMtx (:244-270) and ProcessMVDR (:124-205) as separately callable entries
+    (jdsp_mvdr_estimate_corr / jdsp_mvdr_apply): the first ADDS a frame's contribution to the caller's matrix,
+    the second takes its weights from the caller's matrix -- in main()'s order or not."""
+    L, R = stereo(31, 12)
+    m = eng.mvdr(2.5e-4)
+    # apply with a hand-set matrix, no estimate ever called
+    corr = np.array([4.0e6, 1.5e5, -2.5e5, 3.0e6])
+    out, pre = m.apply(L[:5 * 512], R[:5 * 512], corr, want_precast=True)
+    o_out, o_pre = oracle.mvdr_apply(L[:5 * 512], R[:5 * 512], corr, 2.5e-4)
+    check(out, pre, o_out, o_pre)
+    assert out.size == 4 * 512                                               # :201-204: the first call returns false
+    # estimate accumulates into whatever the caller holds; frames need not be consecutive blocks
+    frames_l = np.stack([np.concatenate([L[3 * 512:4 * 512], L[4 * 512:5 * 512]]), np.concatenate([L[7 * 512:8 * 512], L[5 * 512:6 * 512]])])
+    frames_r = np.stack([np.concatenate([R[3 * 512:4 * 512], R[4 * 512:5 * 512]]), np.concatenate([R[7 * 512:8 * 512], R[5 * 512:6 * 512]])])
+    got = m.estimate_corr(frames_l, frames_r, corr)
+    want = oracle.mvdr_estimate(frames_l[1], frames_r[1], oracle.mvdr_estimate(frames_l[0], frames_r[0], corr))
+    assert np.abs(got - want).max() <= TOL * np.abs(want).max()
+    assert np.abs(got - corr).max() > 1e3                                     # something was added
+    one = m.estimate_corr(frames_l[0], frames_r[0], np.zeros(4))
+    assert np.abs(one - oracle.mvdr_estimate(frames_l[0], frames_r[0], np.zeros(4))).max() <= TOL * np.abs(one).max()
+    # the stream continues (keep buffers carried) with the new matrix
+    out2, pre2 = m.apply(L[5 * 512:9 * 512], R[5 * 512:9 * 512], got, want_precast=True)
+    st_out, st_pre = oracle.mvdr_apply(L[4 * 512:9 * 512], R[4 * 512:9 * 512], want, 2.5e-4)    # block 4 primes the keep buffers
+    check(out2, pre2, st_out, st_pre)
+    # a singular matrix gives the reference's NaN -> 0 samples
+    z, zp = m.apply(L[9 * 512:11 * 512], R[9 * 512:11 * 512], np.zeros(4), want_precast=True)
+    assert not np.isfinite(zp).any() and not z.any()
+    m.close()
