@@ -155,6 +155,13 @@ int jdsp_stft_i16(jdsp_ctx *ctx, const int16_t *pcm_host, long n_samples,
 enum { JDSP_SPECSUB = 0, JDSP_WIENER = 1 };
 typedef struct jdsp_denoise jdsp_denoise;
 int jdsp_denoise_create(jdsp_ctx *ctx, int mode, jdsp_denoise **out);
+/* The same object with the reference's macros as parameters: FFT_PROCESSING_SIZE = n_fft, BLOCK_LEN =
+ * KEEP_LEN = hop (SS:53-55 / WF:42-44 are 1024 / 512 / 512 = jdsp_denoise_create; BASELINE config 3 words the workload
+ * "512-pt STFT 50 % hop" = (512, 256)).  Blocks are then hop samples long everywhere below, the noise estimate has
+ * n_fft entries, and the thresholds stay the reference's (energy 700, ZCR 200, latch at run length 10).  Supported:
+ * (1024, 512) and (512, 256); jdsp_denoise_apply and the sharded entries take 1024-point streams only. */
+int jdsp_denoise_create_cfg(jdsp_ctx *ctx, int mode, int n_fft, int hop, jdsp_denoise **out);
+int jdsp_denoise_block_len(const jdsp_denoise *h);
 int jdsp_denoise_destroy(jdsp_denoise *h);
 int jdsp_denoise_reset(jdsp_denoise *h);                       /* back to a fresh stream */
 int jdsp_denoise_set_option(jdsp_denoise *h, const char *name, long value);   /* "blocks_per_wave" */

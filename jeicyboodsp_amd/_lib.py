@@ -62,6 +62,8 @@ def _load():
         "jdsp_dft_direct_f64": (i, [vp, i, vp, vp, i, l]),
         "jdsp_dft_direct_f64_dev": (i, [vp, i, vp, vp, i, l]),
         "jdsp_denoise_create": (i, [vp, i, C.POINTER(vp)]),
+        "jdsp_denoise_create_cfg": (i, [vp, i, i, i, C.POINTER(vp)]),
+        "jdsp_denoise_block_len": (i, [vp]),
         "jdsp_denoise_destroy": (i, [vp]),
         "jdsp_denoise_reset": (i, [vp]),
         "jdsp_denoise_set_option": (i, [vp, C.c_char_p, l]),

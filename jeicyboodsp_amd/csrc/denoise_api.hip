@@ -20,11 +20,17 @@ static void free_workspace(jdsp_denoise *h)
 
 extern "C" {
 
-int jdsp_denoise_create(jdsp_ctx *ctx, int mode, jdsp_denoise **out)
+int jdsp_denoise_create(jdsp_ctx *ctx, int mode, jdsp_denoise **out) { return jdsp_denoise_create_cfg(ctx, mode, 1024, 512, out); }
+
+int jdsp_denoise_block_len(const jdsp_denoise *h) { return h ? h->block : 0; }
+
+int jdsp_denoise_create_cfg(jdsp_ctx *ctx, int mode, int n_fft, int hop, jdsp_denoise **out)
 {
     if (!ctx || !out) return JDSP_EINVAL;
     *out = nullptr;
     if (mode != JDSP_SPECSUB && mode != JDSP_WIENER) return fail(ctx, JDSP_EINVAL, "jdsp_denoise_create: mode");
+    if (!((n_fft == 1024 && hop == 512) || (n_fft == 512 && hop == 256)))
+        return fail(ctx, JDSP_EINVAL, "jdsp_denoise_create_cfg: (n_fft, hop) must be (1024, 512) or (512, 256)");
     JDSP_HIP(ctx, hipSetDevice(ctx->device));
     int rc = jdsp::ensure_stft1024_table(ctx);
     if (rc) return rc;
@@ -32,7 +38,24 @@ int jdsp_denoise_create(jdsp_ctx *ctx, int mode, jdsp_denoise **out)
     if (!h) return fail(ctx, JDSP_ENOMEM, "jdsp_denoise_create");
     h->ctx = ctx;
     h->mode = mode;
+    h->n_fft = n_fft;
+    h->block = hop;
     hipError_t e = hipSuccess;
+    if (n_fft == 512) {
+        // Hamming over 512 points exactly as the reference writes it (SS:226, PI 3.141592): the VAD's FP64 second half
+        // (SS:131: the first half multiplies the never-updated, all-zero keep buffer) and the halved FP32 window
+        double w_hi[256];
+        float w_h[512];
+        for (int i = 0; i < 512; i++) {
+            const double w = (0.54 - 0.46 * cos(2 * 3.141592 * i / (512 - 1)));
+            w_h[i] = (float)(0.5 * w);
+            if (i >= 256) w_hi[i - 256] = w;
+        }
+        e = hipMalloc((void **)&h->w_hi256, sizeof(w_hi));
+        if (e == hipSuccess) e = hipMalloc((void **)&h->win512h, sizeof(w_h));
+        if (e == hipSuccess) e = hipMemcpy(h->w_hi256, w_hi, sizeof(w_hi), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(h->win512h, w_h, sizeof(w_h), hipMemcpyHostToDevice);
+    }
     for (int i = 0; i < 2 && e == hipSuccess; i++) e = hipMalloc((void **)&h->st[i], sizeof(jdsp::DenoiseState));
     if (e == hipSuccess) e = hipMalloc((void **)&h->plan, sizeof(jdsp::DenoisePlan));
     if (e == hipSuccess) e = hipMalloc((void **)&h->sh_range, 4 * sizeof(int));
@@ -66,6 +89,8 @@ int jdsp_denoise_destroy(jdsp_denoise *h)
     if (h->sh_range) (void)hipFree(h->sh_range);
     if (h->sh_a_in) (void)hipFree(h->sh_a_in);
     if (h->sh_zero_run) (void)hipFree(h->sh_zero_run);
+    if (h->w_hi256) (void)hipFree(h->w_hi256);
+    if (h->win512h) (void)hipFree(h->win512h);
     delete h;
     return JDSP_OK;
 }
@@ -157,6 +182,20 @@ int jdsp_denoise_process_dev(jdsp_denoise *h, const int16_t *pcm_dev, long n_blo
     const jdsp::DenoiseState *st_in = h->st[h->cur];
     jdsp::DenoiseState *st_out = h->st[h->cur ^ 1];
     hipStream_t s = ctx->stream;
+    if (h->n_fft == 512) {
+        if (jdsp::launch_vad256(s, pcm_dev, n_blocks, h->w_hi256, h->flags, h->dbg_energy, h->dbg_zcr) ||
+            jdsp::launch_denoise_plan(s, h->flags, n_blocks, st_in, st_out, h->ver_base, h->snap_mask, h->events, h->ev_n,
+                                      h->plan) ||
+            jdsp::launch_noise_estimate512(s, pcm_dev, n_blocks, st_in, st_out, h->events, h->ev_n, h->plan,
+                                           ctx->stft1024_table, h->win512h, h->mag, h->rows) ||
+            jdsp::launch_denoise512(s, h->mode, pcm_dev, n_blocks, h->calls, st_in, st_out, h->ver_base, h->snap_mask,
+                                    h->rows, ctx->stft1024_table, h->win512h, out_dev, precast_dev))
+            return fail(ctx, JDSP_EHIP, "denoise512 launch", hipGetLastError());
+        h->cur ^= 1;
+        h->calls += n_blocks;
+        h->last_blocks = n_blocks;
+        return JDSP_OK;
+    }
     if (jdsp::launch_vad(s, pcm_dev, n_blocks, h->w_hi, 1, h->flags, h->dbg_energy, h->dbg_zcr) ||
         jdsp::launch_denoise_plan(s, h->flags, n_blocks, st_in, st_out, h->ver_base, h->snap_mask, h->events, h->ev_n,
                                   h->plan) ||
@@ -182,8 +221,9 @@ int jdsp_denoise_process(jdsp_denoise *h, const int16_t *pcm_host, long n_blocks
     if (n_blocks == 0) return JDSP_OK;
     if (!pcm_host || (n_out > 0 && !out_host)) return fail(ctx, JDSP_EINVAL, "jdsp_denoise_process: NULL buffer");
     JDSP_HIP(ctx, hipSetDevice(ctx->device));
-    const size_t in_b = (size_t)n_blocks * 512 * sizeof(int16_t);
-    const size_t out_b = (size_t)(n_out > 0 ? n_out : 1) * 512 * sizeof(int16_t);
+    const size_t blk = (size_t)h->block;
+    const size_t in_b = (size_t)n_blocks * blk * sizeof(int16_t);
+    const size_t out_b = (size_t)(n_out > 0 ? n_out : 1) * blk * sizeof(int16_t);
     int16_t *d_in = nullptr, *d_out = nullptr;
     float *d_pre = nullptr;
     hipError_t e = hipMalloc((void **)&d_in, in_b);
@@ -195,10 +235,10 @@ int jdsp_denoise_process(jdsp_denoise *h, const int16_t *pcm_host, long n_blocks
         rc = fail(ctx, JDSP_EHIP, "jdsp_denoise_process: H2D", e);
     if (!rc) rc = jdsp_denoise_process_dev(h, d_in, n_blocks, d_out, d_pre, nullptr);
     if (!rc && n_out > 0 &&
-        (e = hipMemcpyAsync(out_host, d_out, (size_t)n_out * 1024, hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess)
+        (e = hipMemcpyAsync(out_host, d_out, (size_t)n_out * blk * 2, hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess)
         rc = fail(ctx, JDSP_EHIP, "jdsp_denoise_process: D2H", e);
     if (!rc && n_out > 0 && precast_host &&
-        (e = hipMemcpyAsync(precast_host, d_pre, (size_t)n_out * 2048, hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess)
+        (e = hipMemcpyAsync(precast_host, d_pre, (size_t)n_out * blk * 4, hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess)
         rc = fail(ctx, JDSP_EHIP, "jdsp_denoise_process: D2H", e);
     if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess && !rc) rc = fail(ctx, JDSP_EHIP, "jdsp_denoise_process: sync", e);
     if (d_in) (void)hipFree(d_in);
@@ -213,6 +253,7 @@ int jdsp_denoise_apply(jdsp_denoise *h, const int16_t *pcm_host, long n_blocks, 
     if (!h) return JDSP_EINVAL;
     jdsp_ctx *ctx = h->ctx;
     if (n_blocks < 0 || !noise_host) return fail(ctx, JDSP_EINVAL, "jdsp_denoise_apply: bad argument");
+    if (h->n_fft != 1024) return fail(ctx, JDSP_EINVAL, "jdsp_denoise_apply: 1024-point streams only");
     const long n_out = jdsp_denoise_blocks_out(h, n_blocks);
     if (n_out_blocks) *n_out_blocks = n_out;
     if (n_blocks == 0) return JDSP_OK;
@@ -295,6 +336,7 @@ int jdsp_denoise_shard_vad_dev(jdsp_denoise *h, const int16_t *pcm_ext_dev, long
 {
     if (!h) return JDSP_EINVAL;
     jdsp_ctx *ctx = h->ctx;
+    if (h->n_fft != 1024) return fail(ctx, JDSP_EINVAL, "jdsp_denoise_shard_*: 1024-point streams only");
     if (!(0 <= ext0 && ext0 <= b0 && b0 <= b1 && b1 <= n_total) || (b0 >= 2 ? ext0 != b0 - 2 : ext0 != 0))
         return fail(ctx, JDSP_EINVAL, "jdsp_denoise_shard_vad: need ext0 = max(b0-2, 0) <= b0 <= b1 <= n_total");
     if (b1 > b0 && (!pcm_ext_dev || !flags_own_dev)) return fail(ctx, JDSP_EINVAL, "jdsp_denoise_shard_vad: NULL buffer");
@@ -384,7 +426,7 @@ int jdsp_denoise_noise(jdsp_denoise *h, double *noise_host)
     float tmp[1024];
     JDSP_HIP(ctx, hipMemcpyAsync(tmp, h->st[h->cur]->noise, sizeof(tmp), hipMemcpyDeviceToHost, ctx->stream));
     JDSP_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    for (int i = 0; i < 1024; i++) noise_host[i] = tmp[i];
+    for (int i = 0; i < h->n_fft; i++) noise_host[i] = tmp[i];
     return JDSP_OK;
 }
 

@@ -27,22 +27,31 @@ namespace jdsp {
 // (the next sample is not windowed yet, SS:139).  E > 700 <=> sum s^2 > 716800 exactly.
 constexpr int kVadBlocksPerWave = 8;     // the FP64 window slice (64 B per lane) is loaded once per wave
 
+// SPL = samples per lane = BLOCK_LEN / 64: 8 for the reference's 512-sample blocks (SS:54), 4 for 256-sample blocks
+// (FFT_PROCESSING_SIZE 512, BASELINE config 3 as worded).  dEnergy = sum / (2 BLOCK_LEN) > 700 (SS:143,147,48).
+template <int SPL>
 __global__ __launch_bounds__(64) void vad_kernel(const short *__restrict__ pcm, long n_blocks,
                                                  const double *__restrict__ w_hi, int use_zcr,
                                                  unsigned char *__restrict__ flags,
                                                  long long *__restrict__ dbg_energy, int *__restrict__ dbg_zcr)
 {
+    static_assert(SPL == 8 || SPL == 4, "block of 512 or 256 samples");
     const int lane = threadIdx.x;
     const long b0 = (long)blockIdx.x * kVadBlocksPerWave;
     if (b0 >= n_blocks) return;
-    double w[8];
+    double w[SPL];
 #pragma unroll
-    for (int k = 0; k < 8; k++) w[k] = w_hi[8 * lane + k];
+    for (int k = 0; k < SPL; k++) w[k] = w_hi[SPL * lane + k];
     u32x4 img[kVadBlocksPerWave];
 #pragma unroll
     for (int i = 0; i < kVadBlocksPerWave; i++) {
         const long b = b0 + i < n_blocks ? b0 + i : n_blocks - 1;
-        img[i] = reinterpret_cast<const u32x4 *>(pcm + b * 512)[lane];
+        if (SPL == 8) {
+            img[i] = reinterpret_cast<const u32x4 *>(pcm + b * 512)[lane];
+        } else {
+            const uint2 h = reinterpret_cast<const uint2 *>(pcm + b * 256)[lane];
+            img[i].x = h.x; img[i].y = h.y; img[i].z = 0u; img[i].w = 0u;
+        }
     }
 #pragma unroll
     for (int i = 0; i < kVadBlocksPerWave; i++) {
@@ -53,15 +62,15 @@ __global__ __launch_bounds__(64) void vad_kernel(const short *__restrict__ pcm, 
         x[2] = (short)(img[i].y & 0xffffu); x[3] = (int)img[i].y >> 16;
         x[4] = (short)(img[i].z & 0xffffu); x[5] = (int)img[i].z >> 16;
         x[6] = (short)(img[i].w & 0xffffu); x[7] = (int)img[i].w >> 16;
-        x[8] = __shfl_down(x[0], 1);                   // first sample of the next lane
-        if (lane == 63) x[8] = 0;                      // block sample 512 does not exist: frame[1024], defined 0
+        x[SPL] = __shfl_down(x[0], 1);                 // first sample of the next lane
+        if (lane == 63) x[SPL] = 0;                    // the sample past the block does not exist: frame[N], defined 0
         // s and x are 16-bit quantities: 24-bit multiplies (full rate; the 32-bit v_mul_lo is quarter rate) are
         // exact, and four squares (< 2^30 each) fit an unsigned 32-bit partial sum
         long long e = 0;
         unsigned int q4 = 0;
         int z = 0;
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
+        for (int k = 0; k < SPL; k++) {
             const int s = (int)((double)x[k] * w[k]);  // (short)(short * double), in range
             q4 += (unsigned int)__mul24(s, s);
             if ((k & 3) == 3) { e += (long long)q4; q4 = 0; }
@@ -74,7 +83,7 @@ __global__ __launch_bounds__(64) void vad_kernel(const short *__restrict__ pcm, 
         }
         if (lane == 0) {
             // SS:147 with THRESHOLD_OF_ENERGY 700, _ZCR 200; BeamForming_MVDR_ver1.cpp:233 tests the energy only
-            flags[b] = (e > 716800LL || (use_zcr && z < 200)) ? 1 : 0;
+            flags[b] = (e > 700LL * 128 * SPL || (use_zcr && z < 200)) ? 1 : 0;
             if (dbg_energy) dbg_energy[b] = e;
             if (dbg_zcr) dbg_zcr[b] = z;
         }
@@ -658,9 +667,19 @@ int launch_vad(hipStream_t s, const short *pcm, long n_blocks, const double *w_h
                long long *dbg_energy, int *dbg_zcr)
 {
     if (n_blocks <= 0) return 0;
-    hipLaunchKernelGGL(vad_kernel, dim3((unsigned)((n_blocks + kVadBlocksPerWave - 1) / kVadBlocksPerWave)), dim3(64), 0,
+    hipLaunchKernelGGL(vad_kernel<8>, dim3((unsigned)((n_blocks + kVadBlocksPerWave - 1) / kVadBlocksPerWave)), dim3(64), 0,
                        s, pcm, n_blocks, w_hi, use_zcr, flags,
                        dbg_energy, dbg_zcr);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// 256-sample blocks (frames of 512): w_hi = the second half of Hamming(512), 256 doubles
+int launch_vad256(hipStream_t s, const short *pcm, long n_blocks, const double *w_hi, unsigned char *flags,
+                  long long *dbg_energy, int *dbg_zcr)
+{
+    if (n_blocks <= 0) return 0;
+    hipLaunchKernelGGL(vad_kernel<4>, dim3((unsigned)((n_blocks + kVadBlocksPerWave - 1) / kVadBlocksPerWave)), dim3(64), 0,
+                       s, pcm, n_blocks, w_hi, 1, flags, dbg_energy, dbg_zcr);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
@@ -737,6 +756,266 @@ int launch_denoise(hipStream_t s, int mode, int k_opt, const short *pcm, long n_
         }
     }
 #undef JDSP_DN
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// =======================================================================================
+// FFT_PROCESSING_SIZE 512, BLOCK_LEN = KEEP_LEN 256 -- the same programs with the macros of SS:53-55 / WF:42-44 at
+// half their values, which is how BASELINE config 3 words the workload ("512-pt STFT 50 % hop").
+//
+// A 512-sample real frame is half of the wave transform's work, so TWO consecutive frames ride one 512-point
+// complex transform: z[n] = a[n] + j b[n] (both already windowed), Z = FFT512(z), and
+//     A[k] = (Z[k] + conj Z[512-k]) / 2,      B[k] = -j (Z[k] - conj Z[512-k]) / 2
+// are the two frames' spectra (the 1/2 is folded into the window table, as everywhere).  Every lane owns the bin
+// pairs (k, 512-k), k = lane + 64 q, so A[512-k] = conj A[k] costs nothing; the per-bin gain (SS:233-242 /
+// WF:196-213) is applied to both frames and to both bins of a pair with their own N[k], N[512-k]; the gained
+// spectra go back into ONE inverse transform as Y = Ya + j Yb, whose real and imaginary parts are the two frames'
+// time signals (both spectra are Hermitian).  Overlap-add with hop 256 pairs "lane + 64 d" registers exactly as
+// the 1024-point kernel does with hop 512: y[d], d < 4, is the first half of a frame, y[d + 4] its second half.
+//
+// One wave owns 2 kDn512Pairs - 1 consecutive blocks: pairs (j0-1, j0), (j0+1, j0+2), ...; the first frame of the
+// first pair is the halo that rebuilds the overlap tail (its output block belongs to the previous wave).
+constexpr int kDn512Pairs = 4;
+constexpr int kDn512BlocksPerWave = 2 * kDn512Pairs - 1;
+
+// Sample s of this call's stream; s in [-256, 0) is the previous call's last block (state), anything else
+// outside the call is silence.  s = base + lane + 64 t with base a multiple of 256: every branch is wave-uniform.
+__device__ __forceinline__ float dn512_sample(const short *__restrict__ pcm, long n_samples,
+                                              const DenoiseState *__restrict__ st_in, long s)
+{
+    if (s >= 0) return s < n_samples ? (float)pcm[s] : 0.f;
+    if (s >= -256 && st_in) return (float)st_in->prev[256 + s];
+    return 0.f;
+}
+
+// z = (a + j b) * window -> natural-order image of Zh = FFT512(z) in LDS (slot 512 = slot 0)
+__device__ __forceinline__ void dn512_forward(const float (&xa)[8], const float (&xb)[8], const float (&win)[8],
+                                              const WaveTwiddles &tw, float2 *lds, int lane)
+{
+    float2 v[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) v[r] = make_float2(xa[r] * win[r], xb[r] * win[r]);
+    wave_fft512<false>(v, lds, lane, tw);
+    store_natural_image(lds, lane, v);
+    wave_lds_fence();
+}
+
+// |A[k]|, |B[k]| of the frame pair for every bin (A12 on 512-point frames): events e and e+1 share a transform
+__global__ __launch_bounds__(64) void noise_mag512_kernel(const short *__restrict__ pcm, long n_blocks,
+                                                          const DenoiseState *__restrict__ st_in,
+                                                          const int *__restrict__ events,
+                                                          const DenoisePlan *__restrict__ plan,
+                                                          const float2 *__restrict__ table,
+                                                          const float *__restrict__ win512, float *__restrict__ mag)
+{
+    __shared__ __attribute__((aligned(16))) float2 lds[kWaveLdsComplex];
+    const int lane = threadIdx.x;
+    const int n_events = plan->n_events;
+    const int n_pairs = (n_events + 1) >> 1;
+    if ((int)blockIdx.x >= n_pairs) return;
+    WaveTwiddles tw;
+    load_wave_twiddles(tw, table, lane);
+    float win[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) win[r] = win512[lane + 64 * r];
+    const long n_samples = n_blocks * 256;
+    for (int p = blockIdx.x; p < n_pairs; p += gridDim.x) {
+        const int ea = 2 * p, eb = 2 * p + 1 < n_events ? 2 * p + 1 : 2 * p;
+        const long sa = ((long)events[ea] - 1) * 256, sb = ((long)events[eb] - 1) * 256;   // [previous block, block] (SS:165-170)
+        float xa[8], xb[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            xa[r] = dn512_sample(pcm, n_samples, st_in, sa + lane + 64 * r);
+            xb[r] = dn512_sample(pcm, n_samples, st_in, sb + lane + 64 * r);
+        }
+        dn512_forward(xa, xb, win, tw, lds, lane);
+        float *da = mag + (size_t)ea * 1024, *db = mag + (size_t)eb * 1024;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int k = lane + 64 * q;
+            const float2 zk = lds[k], zm = lds[512 - k];
+            const float2 A = cadd_conj(zk, zm), B = csub_conj_mj(zk, zm);
+            const float ma = sqrtf(A.x * A.x + A.y * A.y), mb = sqrtf(B.x * B.x + B.y * B.y);
+            da[k] = ma; da[(512 - k) & 511] = ma;                 // |X[512-k]| = |conj X[k]|
+            if (eb != ea) { db[k] = mb; db[(512 - k) & 511] = mb; }
+        }
+        if (lane == 0) {
+            const float2 z = lds[256];
+            da[256] = fabsf(2.f * z.x);
+            if (eb != ea) db[256] = fabsf(2.f * z.y);
+        }
+        wave_lds_fence();
+    }
+}
+
+template <int MODE>
+__device__ __forceinline__ void dn512_pair(const float (&xa)[8], const float (&xb)[8], const float (&win)[8],
+                                           const WaveTwiddles &tw, float2 *lds, int lane,
+                                           const float *__restrict__ na, const float *__restrict__ nb, float2 (&y)[8])
+{
+    dn512_forward(xa, xb, win, tw, lds, lane);
+    float2 yk[4], ym[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int k = lane + 64 * q, m = (512 - k) & 511;
+        const float2 zk = lds[k], zm = lds[512 - k];
+        const float2 A = cadd_conj(zk, zm), B = csub_conj_mj(zk, zm);
+        // bin k of both frames, and bin 512-k (= the conjugates) with ITS noise values
+        const float2 ak = apply_gain<MODE>(A, na[k]), bk = apply_gain<MODE>(B, nb[k]);
+        const float2 am = apply_gain<MODE>(A, na[m]), bm = apply_gain<MODE>(B, nb[m]);
+        yk[q] = cadd_pj(ak, bk);                                  // Ya[k] + j Yb[k]
+        const float2 t = cadd_mj(am, bm);                         // conj(Ya) + j conj(Yb) = conj(Ya - j Yb)
+        ym[q] = make_float2(t.x, -t.y);
+    }
+    float2 y256;
+    {
+        const float2 z = lds[256];                                // self-mirrored bin: A = 2 Re z, B = 2 Im z, both real
+        const float2 a = apply_gain<MODE>(make_float2(2.f * z.x, 0.f), na[256]);
+        const float2 b = apply_gain<MODE>(make_float2(2.f * z.y, 0.f), nb[256]);
+        y256 = cadd_pj(a, b);
+    }
+    wave_lds_fence();
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int k = lane + 64 * q;
+        lds[512 - k] = ym[q];                                     // k = 0 lands in the spare slot 512
+        lds[k] = yk[q];
+    }
+    if (lane == 0) lds[256] = y256;
+    wave_lds_fence();
+#pragma unroll
+    for (int r = 0; r < 8; r++) y[r] = lds[lane + 64 * r];
+    wave_lds_fence();
+    wave_fft512<true>(y, lds, lane, tw);
+    // the reference's 1/N after FFTW's unnormalised inverse (SS:248) with N = 512; a power of two, exact
+#pragma unroll
+    for (int d = 0; d < 8; d++) y[d] = make_float2(y[d].x * (1.0f / 512.0f), y[d].y * (1.0f / 512.0f));
+    wave_lds_fence();
+}
+
+template <int MODE>
+__global__ __launch_bounds__(64, 3) void denoise512_kernel(
+    const short *__restrict__ pcm, long n_blocks, long calls_before, const DenoiseState *__restrict__ st_in,
+    DenoiseState *st_out, const int *__restrict__ ver_base, const unsigned long long *__restrict__ snap_mask,
+    const float *__restrict__ noise_rows, const float2 *__restrict__ table, const float *__restrict__ win512,
+    short *__restrict__ out, float *__restrict__ precast, DenoiseShard sh)
+{
+    __shared__ __attribute__((aligned(16))) float2 lds[kWaveLdsComplex];
+    const int lane = threadIdx.x;
+    const long per_xcd = (gridDim.x + 7) >> 3;                // XCD-aware chunk order (speed only)
+    const long j0 = ((long)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3)) * kDn512BlocksPerWave;
+    if (j0 >= n_blocks) return;
+    const long n_samples = n_blocks * 256;
+    WaveTwiddles tw;
+    load_wave_twiddles(tw, table, lane);
+    float win[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) win[r] = win512[lane + 64 * r];
+
+    // samples base + lane + 64 t: frame (j0 - 1 + 2p) starts at t = 8 p, frame (j0 + 2p) at t = 8 p + 4
+    float xs[8 * kDn512Pairs + 4];
+    const long base = (j0 - 2) * 256;
+#pragma unroll
+    for (int t = 0; t < 8 * kDn512Pairs + 4; t++) xs[t] = dn512_sample(pcm, n_samples, st_in, base + lane + 64 * t);
+
+    float tail[4];
+    const long first_emit = sh.emit_from;
+#pragma unroll
+    for (int p = 0; p < kDn512Pairs; p++) {
+        const long ja = j0 - 1 + 2 * p, jb = ja + 1;
+        if (ja >= n_blocks) break;
+        float xa[8], xb[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) { xa[r] = xs[8 * p + r]; xb[r] = xs[8 * p + 4 + r]; }
+        float2 y[8];
+        dn512_pair<MODE>(xa, xb, win, tw, lds, lane, noise_row(noise_rows, ver_base, snap_mask, ja >= 0 ? ja : 0, sh),
+                         noise_row(noise_rows, ver_base, snap_mask, jb < n_blocks ? jb : n_blocks - 1, sh), y);
+        // the very first call of a stream only stashes its block (SS:211-216): no transform, empty overlap
+        const bool a_void = calls_before + ja <= 0, b_void = calls_before + jb <= 0;
+        float oa[4], ob[4];
+        if (p == 0) {
+            // frame ja = j0 - 1 is the halo: its block belongs to the previous wave (or call); only its second half counts
+            if (j0 == 0) {
+#pragma unroll
+                for (int d = 0; d < 4; d++) tail[d] = st_in->tail[lane + 64 * d];       // rgsdOveraped carried over
+            } else {
+#pragma unroll
+                for (int d = 0; d < 4; d++) tail[d] = a_void ? 0.f : y[d + 4].x;
+            }
+        } else {
+#pragma unroll
+            for (int d = 0; d < 4; d++) {
+                oa[d] = tail[d] + (a_void ? 0.f : y[d].x);                              // SS:248 overlap-add
+                tail[d] = a_void ? 0.f : y[d + 4].x;                                    // SS:255-256
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < 4; d++) ob[d] = tail[d] + (b_void ? 0.f : y[d].y);
+        float tail_b[4];
+#pragma unroll
+        for (int d = 0; d < 4; d++) tail_b[d] = b_void ? 0.f : y[d + 4].y;
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            const long j = half ? jb : ja;
+            if (half == 0 && p == 0) continue;
+            if (j >= n_blocks) continue;
+            const float *o = half ? ob : oa;
+            if (j >= first_emit && j < sh.emit_to) {
+                const long oi = j - first_emit;
+#pragma unroll
+                for (int d = 0; d < 4; d++) out[oi * 256 + lane + 64 * d] = (short)cast_i16_bits(o[d]);
+                if (precast) {
+#pragma unroll
+                    for (int d = 0; d < 4; d++) precast[oi * 256 + lane + 64 * d] = o[d];
+                }
+            }
+            if (j == n_blocks - 1) {                                                    // SS:257 and the overlap carried out
+#pragma unroll
+                for (int d = 0; d < 4; d++) {
+                    st_out->prev[lane + 64 * d] = pcm[j * 256 + lane + 64 * d];
+                    st_out->tail[lane + 64 * d] = half ? tail_b[d] : tail[d];
+                }
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < 4; d++) tail[d] = tail_b[d];
+    }
+}
+
+int launch_noise_estimate512(hipStream_t s, const short *pcm, long n_blocks, const DenoiseState *st_in,
+                             DenoiseState *st_out, const int *events, const int *ev_n, const DenoisePlan *plan,
+                             const float2 *table, const float *win512, float *mag, float *noise_rows)
+{
+    if (n_blocks > 0) {
+        const long pairs = (n_blocks + 1) / 2;
+        const long grid = pairs < 4096 ? pairs : 4096;
+        hipLaunchKernelGGL(noise_mag512_kernel, dim3((unsigned)grid), dim3(64), 0, s, pcm, n_blocks, st_in, events, plan,
+                           table, win512, mag);
+    }
+    // bins 0..511 only (rows keep the 1024-float pitch of the 1024-point path)
+    hipLaunchKernelGGL(noise_scan_kernel, dim3(2), dim3(256), 0, s, mag, ev_n, plan, st_in, st_out, noise_rows);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+int launch_denoise512(hipStream_t s, int mode, const short *pcm, long n_blocks, long calls_before,
+                      const DenoiseState *st_in, DenoiseState *st_out, const int *ver_base,
+                      const unsigned long long *snap_mask, const float *noise_rows, const float2 *table,
+                      const float *win512, short *out, float *precast)
+{
+    if (n_blocks <= 0) return 0;
+    DenoiseShard sh;
+    sh.ver_block_off = 0;
+    sh.ver_row_off = nullptr;
+    sh.emit_from = calls_before >= 2 ? 0 : 2 - calls_before;
+    sh.emit_to = n_blocks;
+    const long waves = (n_blocks + kDn512BlocksPerWave - 1) / kDn512BlocksPerWave;
+    const long grid = (waves + 7) / 8 * 8;
+    if (mode == 0)
+        hipLaunchKernelGGL(denoise512_kernel<0>, dim3((unsigned)grid), dim3(64), 0, s, pcm, n_blocks, calls_before, st_in,
+                           st_out, ver_base, snap_mask, noise_rows, table, win512, out, precast, sh);
+    else
+        hipLaunchKernelGGL(denoise512_kernel<1>, dim3((unsigned)grid), dim3(64), 0, s, pcm, n_blocks, calls_before, st_in,
+                           st_out, ver_base, snap_mask, noise_rows, table, win512, out, precast, sh);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

@@ -118,6 +118,15 @@ int launch_dft_direct_f64(hipStream_t stream, int kind, const void *in, double2 
 // denoise_kernels.hip
 int launch_vad(hipStream_t s, const short *pcm, long n_blocks, const double *w_hi, int use_zcr, unsigned char *flags,
                long long *dbg_energy, int *dbg_zcr);
+int launch_vad256(hipStream_t s, const short *pcm, long n_blocks, const double *w_hi, unsigned char *flags,
+                  long long *dbg_energy, int *dbg_zcr);
+int launch_noise_estimate512(hipStream_t s, const short *pcm, long n_blocks, const DenoiseState *st_in,
+                             DenoiseState *st_out, const int *events, const int *ev_n, const DenoisePlan *plan,
+                             const float2 *table, const float *win512, float *mag, float *noise_rows);
+int launch_denoise512(hipStream_t s, int mode, const short *pcm, long n_blocks, long calls_before,
+                      const DenoiseState *st_in, DenoiseState *st_out, const int *ver_base,
+                      const unsigned long long *snap_mask, const float *noise_rows, const float2 *table,
+                      const float *win512, short *out, float *precast);
 int launch_run_plan(hipStream_t s, const unsigned char *flags, long n_blocks, const int *run_len_in, int *run_len_out,
                     int latch_run, int *ver_base, unsigned long long *snap_mask, int *events, int *ev_n,
                     DenoisePlan *plan);
@@ -226,6 +235,9 @@ struct jdsp_denoise {
     float *mag = nullptr, *rows = nullptr;
     long last_blocks = 0;
     int opt_k = 0;
+    int n_fft = 1024, block = 512;        // FFT_PROCESSING_SIZE, BLOCK_LEN = KEEP_LEN (SS:53-55); 512 / 256 also built
+    double *w_hi256 = nullptr;            // 512-point frames: second half of the FP64 Hamming(512) (VAD)
+    float *win512h = nullptr;             // 512-point frames: 0.5 * Hamming(512), natural order
     // sharded (multi-GPU) run in progress: jdsp_denoise_shard_*
     long sh_ext0 = 0, sh_b0 = 0, sh_b1 = 0, sh_total = 0;
     const int16_t *sh_pcm = nullptr;

@@ -74,8 +74,8 @@ class Engine:
     def hmm(self, models):
         return Hmm(self, models)
 
-    def denoiser(self, mode):
-        return Denoiser(self, mode)
+    def denoiser(self, mode, n_fft=1024, hop=512):
+        return Denoiser(self, mode, n_fft, hop)
 
     def synchronize(self):
         self._ck(L.jdsp_synchronize(self._h))
@@ -214,11 +214,12 @@ class Denoiser:
     SpectralSubtraction_final.cpp:92-113 / WienerFilter_final.cpp:91-112 for batches of blocks."""
     SPECSUB, WIENER = 0, 1
 
-    def __init__(self, engine, mode):
+    def __init__(self, engine, mode, n_fft=1024, hop=512):
         self.eng = engine
         h = C.c_void_p()
-        engine._ck(L.jdsp_denoise_create(engine._h, int(mode), C.byref(h)))
+        engine._ck(L.jdsp_denoise_create_cfg(engine._h, int(mode), int(n_fft), int(hop), C.byref(h)))
         self._h = h
+        self.n_fft, self.block = int(n_fft), L.jdsp_denoise_block_len(h)
         engine._children.append(self)
 
     def close(self):
@@ -244,31 +245,32 @@ class Denoiser:
         return L.jdsp_denoise_blocks_out(self._h, n_blocks)
 
     def process(self, pcm, want_precast=False):
-        """pcm: int16, a whole number of 512-sample blocks.  numpy -> host path, torch CUDA -> device path.
-        Returns out (int16) or (out, precast float32)."""
+        """pcm: int16, a whole number of blocks (self.block samples: 512, or 256 for 512-point frames).
+        numpy -> host path, torch CUDA -> device path.  Returns out (int16) or (out, precast float32)."""
+        B = self.block
         if _is_torch(pcm):
             import torch
-            assert pcm.is_cuda and pcm.dtype == torch.int16 and pcm.is_contiguous() and pcm.numel() % 512 == 0
-            nb = pcm.numel() // 512
+            assert pcm.is_cuda and pcm.dtype == torch.int16 and pcm.is_contiguous() and pcm.numel() % B == 0
+            nb = pcm.numel() // B
             n_out = self.blocks_out(nb)
-            out = torch.empty(max(n_out, 1) * 512, dtype=torch.int16, device=pcm.device)
-            pre = torch.empty(max(n_out, 1) * 512, dtype=torch.float32, device=pcm.device) if want_precast else None
+            out = torch.empty(max(n_out, 1) * B, dtype=torch.int16, device=pcm.device)
+            pre = torch.empty(max(n_out, 1) * B, dtype=torch.float32, device=pcm.device) if want_precast else None
             self.eng._use_torch_stream()
             self.eng._ck(L.jdsp_denoise_process_dev(self._h, C.c_void_p(pcm.data_ptr()), nb, C.c_void_p(out.data_ptr()),
                                                     C.c_void_p(pre.data_ptr()) if want_precast else None, None))
-            out = out[:n_out * 512]
-            return (out, pre[:n_out * 512]) if want_precast else out
+            out = out[:n_out * B]
+            return (out, pre[:n_out * B]) if want_precast else out
         pcm = np.ascontiguousarray(pcm, np.int16)
-        assert pcm.size % 512 == 0
-        nb = pcm.size // 512
+        assert pcm.size % B == 0
+        nb = pcm.size // B
         n_out = self.blocks_out(nb)
-        out = np.zeros(max(n_out, 1) * 512, np.int16)
-        pre = np.zeros(max(n_out, 1) * 512, np.float32) if want_precast else None
+        out = np.zeros(max(n_out, 1) * B, np.int16)
+        pre = np.zeros(max(n_out, 1) * B, np.float32) if want_precast else None
         got = C.c_long()
         self.eng._ck(L.jdsp_denoise_process(self._h, pcm.ctypes.data_as(C.c_void_p), nb, out.ctypes.data_as(C.c_void_p),
                                             pre.ctypes.data_as(C.c_void_p) if want_precast else None, C.byref(got)))
         assert got.value == n_out
-        return (out[:n_out * 512], pre[:n_out * 512]) if want_precast else out[:n_out * 512]
+        return (out[:n_out * B], pre[:n_out * B]) if want_precast else out[:n_out * B]
 
     # ---- one rank's share of a global stream (jdsp_denoise_shard_*; driver: sharding.denoise_sharded)
     def shard_vad(self, pcm_ext, ext0, b0, b1, n_total):
@@ -306,7 +308,7 @@ class Denoiser:
         return (out[: n_out * 512], pre[: n_out * 512]) if want_precast else out[: n_out * 512]
 
     def noise(self):
-        n = np.zeros(1024, np.float64)
+        n = np.zeros(self.n_fft, np.float64)
         self.eng._ck(L.jdsp_denoise_noise(self._h, n.ctypes.data_as(C.c_void_p)))
         return n
 

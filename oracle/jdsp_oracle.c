@@ -251,31 +251,38 @@ int orc_vad_block(const short *block, int block_len, double *energy, int *zcr)
 }
 
 /* ------------------------------------------------------------------------- */
-#define DN_BLOCK 512
-#define DN_FFT 1024
+/* BLOCK_LEN = KEEP_LEN and FFT_PROCESSING_SIZE = 2 BLOCK_LEN are macros in the reference (SS:53-55: 512 / 512 /
+ * 1024); here they are a run-time parameter of the stream (BASELINE config 3 words them 256 / 256 / 512). */
+#define DN_BLOCK_MAX 512
+#define DN_FFT_MAX 1024
 struct orc_denoise {
     int mode;
+    int blk, nfft;               /* BLOCK_LEN (= KEEP_LEN), FFT_PROCESSING_SIZE */
     /* main(): SS:68-72 */
     int run_len;                 /* iNumOfIteration */
-    short stash[DN_BLOCK];       /* rgsTempBuffer */
-    double noise[DN_FFT];        /* rgdEstimatedNS */
+    short stash[DN_BLOCK_MAX];   /* rgsTempBuffer */
+    double noise[DN_FFT_MAX];    /* rgdEstimatedNS */
     /* EstimateNoiseSpectrum statics: SS:161,164 */
-    double avg[DN_FFT];
-    short est_keep[DN_BLOCK];
+    double avg[DN_FFT_MAX];
+    short est_keep[DN_BLOCK_MAX];
     /* SpectralSubtraction / WienerFiltering statics: SS:202,208-209 */
     int calls;
-    short keep[DN_BLOCK];
-    double ola[DN_FFT];
+    short keep[DN_BLOCK_MAX];
+    double ola[DN_FFT_MAX];
     int last_voice;
-    orc_cplx a[DN_FFT], b[DN_FFT];
+    orc_cplx a[DN_FFT_MAX], b[DN_FFT_MAX];
 };
 
-orc_denoise *orc_denoise_create(int mode)
+orc_denoise *orc_denoise_create2(int mode, int block_len)
 {
+    if (block_len < 2 || block_len > DN_BLOCK_MAX || (block_len & (block_len - 1))) return NULL;
     orc_denoise *s = (orc_denoise *)calloc(1, sizeof(orc_denoise));
     s->mode = mode;
+    s->blk = block_len;
+    s->nfft = 2 * block_len;
     return s;
 }
+orc_denoise *orc_denoise_create(int mode) { return orc_denoise_create2(mode, 512); }
 void orc_denoise_destroy(orc_denoise *s) { free(s); }
 const double *orc_denoise_noise(const orc_denoise *s) { return s->noise; }
 int orc_denoise_last_voice(const orc_denoise *s) { return s->last_voice; }
@@ -283,28 +290,30 @@ int orc_denoise_last_voice(const orc_denoise *s) { return s->last_voice; }
 /* SS:159-198 == WF:120-159 */
 static void estimate_noise(orc_denoise *s, const short *in)
 {
-    short frame[DN_FFT];
-    if (s->run_len == 2) memcpy(s->est_keep, s->stash, sizeof(s->est_keep));   /* :165-167 */
-    memcpy(frame, s->est_keep, sizeof(s->est_keep));
-    memcpy(frame + DN_BLOCK, in, sizeof(short) * DN_BLOCK);
-    windowed_forward(frame, DN_FFT, s->a, s->b);                               /* :168-180 */
-    for (int i = 0; i < DN_FFT; i++) {                                         /* :182-187 */
+    const int B = s->blk, N = s->nfft;
+    short frame[DN_FFT_MAX];
+    if (s->run_len == 2) memcpy(s->est_keep, s->stash, sizeof(short) * B);     /* :165-167 */
+    memcpy(frame, s->est_keep, sizeof(short) * B);
+    memcpy(frame + B, in, sizeof(short) * B);
+    windowed_forward(frame, N, s->a, s->b);                                    /* :168-180 */
+    for (int i = 0; i < N; i++) {                                              /* :182-187 */
         s->avg[i] += sqrt(s->b[i].re * s->b[i].re + s->b[i].im * s->b[i].im);
         if (s->run_len >= 3) s->avg[i] /= 2.0;
     }
     if (s->run_len == 10)                                                      /* :189-193 */
-        memcpy(s->noise, s->avg, sizeof(s->noise));
-    memcpy(s->est_keep, in, sizeof(s->est_keep));                              /* :195 */
+        memcpy(s->noise, s->avg, sizeof(double) * N);
+    memcpy(s->est_keep, in, sizeof(short) * B);                                /* :195 */
 }
 
 int orc_denoise_block(orc_denoise *s, const short *in, short *out, double *ola_out)
 {
-    short frame[DN_FFT];
+    const int B = s->blk, N = s->nfft;
+    short frame[DN_FFT_MAX];
     /* main loop, SS:98-109 */
-    s->last_voice = orc_vad_block(in, DN_BLOCK, NULL, NULL);
+    s->last_voice = orc_vad_block(in, B, NULL, NULL);
     if (!s->last_voice) {
         s->run_len++;
-        if (s->run_len == 1) memcpy(s->stash, in, sizeof(s->stash));
+        if (s->run_len == 1) memcpy(s->stash, in, sizeof(short) * B);
         else estimate_noise(s, in);
     } else {
         s->run_len = 0;
@@ -312,13 +321,13 @@ int orc_denoise_block(orc_denoise *s, const short *in, short *out, double *ola_o
     /* SS:201-264 / WF:162-235 */
     s->calls++;
     if (s->calls == 1) {                                        /* :211-216 */
-        memcpy(s->keep, in, sizeof(s->keep));
+        memcpy(s->keep, in, sizeof(short) * B);
         return 0;
     }
-    memcpy(frame, s->keep, sizeof(s->keep));
-    memcpy(frame + DN_BLOCK, in, sizeof(short) * DN_BLOCK);
-    windowed_forward(frame, DN_FFT, s->a, s->b);                /* :218-230 */
-    for (int i = 0; i < DN_FFT; i++) {
+    memcpy(frame, s->keep, sizeof(short) * B);
+    memcpy(frame + B, in, sizeof(short) * B);
+    windowed_forward(frame, N, s->a, s->b);                     /* :218-230 */
+    for (int i = 0; i < N; i++) {
         double re = s->b[i].re, im = s->b[i].im;
         double ang = atan2(im, re);                             /* SS:234 / WF:197 */
         double amp;
@@ -333,33 +342,39 @@ int orc_denoise_block(orc_denoise *s, const short *in, short *out, double *ola_o
         s->a[i].re = amp * cos(ang);                            /* SS:240-241 / WF:211-212 */
         s->a[i].im = amp * sin(ang);
     }
-    orc_dft_c2c(s->a, s->b, DN_FFT, +1);                        /* SS:244-245 */
-    for (int i = 0; i < DN_FFT; i++) s->ola[i] += 1. / DN_FFT * s->b[i].re;   /* SS:248 */
-    for (int i = 0; i < DN_BLOCK; i++) {
+    orc_dft_c2c(s->a, s->b, N, +1);                             /* SS:244-245 */
+    for (int i = 0; i < N; i++) s->ola[i] += 1. / N * s->b[i].re;   /* SS:248 */
+    for (int i = 0; i < B; i++) {
         out[i] = cast_i16(s->ola[i]);                           /* SS:252 */
         if (ola_out) ola_out[i] = s->ola[i];
     }
-    memmove(s->ola, s->ola + DN_BLOCK, sizeof(double) * DN_BLOCK);   /* SS:255-256 */
-    memset(s->ola + DN_BLOCK, 0, sizeof(double) * DN_BLOCK);
-    memcpy(s->keep, in, sizeof(s->keep));                       /* SS:257 */
+    memmove(s->ola, s->ola + B, sizeof(double) * B);            /* SS:255-256 */
+    memset(s->ola + B, 0, sizeof(double) * B);
+    memcpy(s->keep, in, sizeof(short) * B);                     /* SS:257 */
     return s->calls >= 3;                                       /* SS:260-263 */
 }
 
-long orc_denoise_stream(int mode, const short *pcm, long n_blocks, short *out, double *ola_out)
+long orc_denoise_stream2(int mode, int block_len, const short *pcm, long n_blocks, short *out, double *ola_out)
 {
-    orc_denoise *s = orc_denoise_create(mode);
-    short blk[DN_BLOCK];
-    double pre[DN_BLOCK];
+    orc_denoise *s = orc_denoise_create2(mode, block_len);
+    short blk[DN_BLOCK_MAX];
+    double pre[DN_BLOCK_MAX];
     long n_out = 0;
+    if (!s) return -1;
     for (long b = 0; b < n_blocks; b++) {
-        if (orc_denoise_block(s, pcm + (size_t)b * DN_BLOCK, blk, pre)) {
-            memcpy(out + (size_t)n_out * DN_BLOCK, blk, sizeof(blk));
-            if (ola_out) memcpy(ola_out + (size_t)n_out * DN_BLOCK, pre, sizeof(pre));
+        if (orc_denoise_block(s, pcm + (size_t)b * block_len, blk, pre)) {
+            memcpy(out + (size_t)n_out * block_len, blk, sizeof(short) * block_len);
+            if (ola_out) memcpy(ola_out + (size_t)n_out * block_len, pre, sizeof(double) * block_len);
             n_out++;
         }
     }
     orc_denoise_destroy(s);
     return n_out;
+}
+
+long orc_denoise_stream(int mode, const short *pcm, long n_blocks, short *out, double *ola_out)
+{
+    return orc_denoise_stream2(mode, 512, pcm, n_blocks, out, ola_out);
 }
 
 /* ------------------------------------------------------------------------- */

@@ -76,6 +76,11 @@ const double *orc_denoise_noise(const orc_denoise *s);
 int orc_denoise_last_voice(const orc_denoise *s);
 /* Whole stream: n_blocks blocks in, returns blocks written (n_blocks-2). */
 long orc_denoise_stream(int mode, const short *pcm, long n_blocks, short *out, double *ola_out);
+/* The same with the reference's macros as parameters: BLOCK_LEN = KEEP_LEN = block_len (a power of two <= 512),
+ * FFT_PROCESSING_SIZE = 2 block_len (SS:53-55 are 512 / 512 / 1024; BASELINE config 3 words them 256 / 256 / 512).
+ * The thresholds (SS:48-49: energy 700, ZCR 200) and NOISE_ESTIMATION_FRAMECOUNT stay as they are. */
+orc_denoise *orc_denoise_create2(int mode, int block_len);
+long orc_denoise_stream2(int mode, int block_len, const short *pcm, long n_blocks, short *out, double *ola_out);
 
 /* Fast_Convolution_Based_3DAudio_Impl.cpp:102-177 overlap-save convolver,
  * generalised: n_fft transform, n_taps filter, block = n_fft - n_taps + 1

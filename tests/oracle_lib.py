@@ -57,6 +57,10 @@ class Oracle:
         L.orc_vad_block.restype = C.c_int
         L.orc_denoise_stream.argtypes = [C.c_int, _c_short_p, C.c_long, _c_short_p, _c_double_p]
         L.orc_denoise_stream.restype = C.c_long
+        L.orc_denoise_stream2.argtypes = [C.c_int, C.c_int, _c_short_p, C.c_long, _c_short_p, _c_double_p]
+        L.orc_denoise_stream2.restype = C.c_long
+        L.orc_denoise_create2.argtypes = [C.c_int, C.c_int]
+        L.orc_denoise_create2.restype = C.c_void_p
         L.orc_denoise_create.argtypes = [C.c_int]
         L.orc_denoise_create.restype = C.c_void_p
         L.orc_denoise_destroy.argtypes = [C.c_void_p]
@@ -195,26 +199,26 @@ class Oracle:
         v = self.lib.orc_vad_block(_p(block, _c_short_p), block.size, C.byref(e), C.byref(z))
         return bool(v), e.value, z.value
 
-    def denoise_stream(self, mode, pcm):
+    def denoise_stream(self, mode, pcm, block=512):
         pcm = np.ascontiguousarray(pcm, np.int16)
-        nb = pcm.size // 512
-        out = np.zeros(max(nb, 1) * 512, np.int16)
-        pre = np.zeros(max(nb, 1) * 512, np.float64)
-        n = self.lib.orc_denoise_stream(mode, _p(pcm, _c_short_p), nb, _p(out, _c_short_p), _p(pre, _c_double_p))
-        return out[:n * 512].copy(), pre[:n * 512].copy()
+        nb = pcm.size // block
+        out = np.zeros(max(nb, 1) * block, np.int16)
+        pre = np.zeros(max(nb, 1) * block, np.float64)
+        n = self.lib.orc_denoise_stream2(mode, block, _p(pcm, _c_short_p), nb, _p(out, _c_short_p), _p(pre, _c_double_p))
+        return out[:n * block].copy(), pre[:n * block].copy()
 
-    def denoise_trace(self, mode, pcm):
+    def denoise_trace(self, mode, pcm, block=512):
         """Block-by-block run that also returns the VAD flags and every latched noise estimate."""
         pcm = np.ascontiguousarray(pcm, np.int16)
-        nb = pcm.size // 512
-        h = self.lib.orc_denoise_create(mode)
-        out, pre, flags, noises, ver = [], [], [], [np.zeros(1024)], []
-        ob = np.zeros(512, np.int16)
-        pb = np.zeros(512, np.float64)
+        nb = pcm.size // block
+        h = self.lib.orc_denoise_create2(mode, block)
+        out, pre, flags, noises, ver = [], [], [], [np.zeros(2 * block)], []
+        ob = np.zeros(block, np.int16)
+        pb = np.zeros(block, np.float64)
         for b in range(nb):
-            blk = pcm[b * 512:(b + 1) * 512]
+            blk = pcm[b * block:(b + 1) * block]
             ok = self.lib.orc_denoise_block(h, _p(blk, _c_short_p), _p(ob, _c_short_p), _p(pb, _c_double_p))
-            cur = np.ctypeslib.as_array(self.lib.orc_denoise_noise(h), shape=(1024,)).copy()
+            cur = np.ctypeslib.as_array(self.lib.orc_denoise_noise(h), shape=(2 * block,)).copy()
             if not np.array_equal(cur, noises[-1]):
                 noises.append(cur)
             ver.append(len(noises) - 1)

@@ -113,6 +113,19 @@ def main():
                    "VAD + plan + noise estimate + fused window/FFT/gain/IFFT/OLA, 65,536 blocks of 512",
                    cpu=cpu_rate(lambda: orc.denoise_stream(mode, x[:1024 * 512]), 1024))
             d.close()
+        # BASELINE config 3 as worded: 512-point frames, hop 256 (two frames per wave transform), 65,536 blocks of 256
+        x5 = pcm_of(rng, B * 256)
+        q = (np.abs(rng.normal(0, 45, 24 * 256)) + 14.0) * np.where(np.arange(24 * 256) % 2 == 0, 1.0, -1.0)
+        x5[:24 * 256] = np.rint(q).astype(np.int16)         # sign-alternating quiet start: ZCR >= 200, so the estimate latches
+        t5 = torch.from_numpy(x5).cuda()
+        for mode, nm in ((0, "specsub"), (1, "wiener")):
+            d = eng.denoiser(mode, 512, 256)
+            d.process(t5)
+            ms = timed(lambda: d.process(t5), a.iters)
+            report("denoise_" + nm + "_512pt_hop256", ms, B, "blocks", 1024, 2 * 5 * 256 * 8 + 2 * 256 * 14,
+                   "BASELINE config 3 as worded: FFT_PROCESSING_SIZE 512, BLOCK_LEN 256; 65,536 blocks of 256",
+                   cpu=cpu_rate(lambda: orc.denoise_stream(mode, x5[:1024 * 256], block=256), 1024))
+            d.close()
     if on("mfcc"):
         x = torch.from_numpy(pcm_of(rng, 512 * (B + 1))).cuda()
         m = eng.mfcc()
