@@ -314,6 +314,12 @@ int jdsp_mvdr_shard_finish_dev(jdsp_mvdr *h, const double *sums_all_dev, int wor
  * pcm: n_mics planes, chan_stride samples apart, each n_blocks*512 samples. 2 <= n_mics <= 8. */
 typedef struct jdsp_mvdrn jdsp_mvdrn;
 int jdsp_mvdrn_create(jdsp_ctx *ctx, int n_mics, const double *delays_s, double loading, jdsp_mvdrn **out);
+/* The same with FFT_PROCESSING_LEN = n_fft: 1024 (= jdsp_mvdrn_create: the reference's frame) or 512 (BASELINE config 5
+ * as worded, "8-mic array, 512-pt STFT": blocks of 256 samples, KEEP_LEN 255, frames [first 255 samples of the previous
+ * block, block, 0], 257 bins at k * 16000 / 512 Hz, R_k += X X^H / 512, samples 255..510 out).  Blocks are then n_fft / 2
+ * samples everywhere below. */
+int jdsp_mvdrn_create_cfg(jdsp_ctx *ctx, int n_mics, const double *delays_s, double loading, int n_fft, jdsp_mvdrn **out);
+int jdsp_mvdrn_block_len(const jdsp_mvdrn *h);
 int jdsp_mvdrn_destroy(jdsp_mvdrn *h);
 int jdsp_mvdrn_reset(jdsp_mvdrn *h);
 long jdsp_mvdrn_blocks_out(const jdsp_mvdrn *h, long n_blocks);

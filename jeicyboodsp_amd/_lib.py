@@ -127,6 +127,8 @@ def _load():
         "jdsp_mvdr_shard_blocks_out": (l, [vp]),
         "jdsp_mvdr_shard_finish_dev": (i, [vp, vp, i, i, vp, vp, C.POINTER(l)]),
         "jdsp_mvdrn_create": (i, [vp, i, vp, C.c_double, C.POINTER(vp)]),
+        "jdsp_mvdrn_create_cfg": (i, [vp, i, vp, C.c_double, i, C.POINTER(vp)]),
+        "jdsp_mvdrn_block_len": (i, [vp]),
         "jdsp_mvdrn_destroy": (i, [vp]),
         "jdsp_mvdrn_reset": (i, [vp]),
         "jdsp_mvdrn_blocks_out": (l, [vp, l]),

@@ -675,11 +675,11 @@ int launch_vad(hipStream_t s, const short *pcm, long n_blocks, const double *w_h
 
 // 256-sample blocks (frames of 512): w_hi = the second half of Hamming(512), 256 doubles
 int launch_vad256(hipStream_t s, const short *pcm, long n_blocks, const double *w_hi, unsigned char *flags,
-                  long long *dbg_energy, int *dbg_zcr)
+                  long long *dbg_energy, int *dbg_zcr, int use_zcr)
 {
     if (n_blocks <= 0) return 0;
     hipLaunchKernelGGL(vad_kernel<4>, dim3((unsigned)((n_blocks + kVadBlocksPerWave - 1) / kVadBlocksPerWave)), dim3(64), 0,
-                       s, pcm, n_blocks, w_hi, 1, flags, dbg_energy, dbg_zcr);
+                       s, pcm, n_blocks, w_hi, use_zcr, flags, dbg_energy, dbg_zcr);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
@@ -854,26 +854,46 @@ __device__ __forceinline__ void dn512_pair(const float (&xa)[8], const float (&x
                                            const float *__restrict__ na, const float *__restrict__ nb, float2 (&y)[8])
 {
     dn512_forward(xa, xb, win, tw, lds, lane);
-    float2 yk[4], ym[4];
+    float2 yka[4], ykb[4], yma[4], ymb[4];
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         const int k = lane + 64 * q, m = (512 - k) & 511;
         const float2 zk = lds[k], zm = lds[512 - k];
         const float2 A = cadd_conj(zk, zm), B = csub_conj_mj(zk, zm);
         // bin k of both frames, and bin 512-k (= the conjugates) with ITS noise values
-        const float2 ak = apply_gain<MODE>(A, na[k]), bk = apply_gain<MODE>(B, nb[k]);
-        const float2 am = apply_gain<MODE>(A, na[m]), bm = apply_gain<MODE>(B, nb[m]);
+        yka[q] = apply_gain<MODE>(A, na[k]); ykb[q] = apply_gain<MODE>(B, nb[k]);
+        yma[q] = apply_gain<MODE>(A, na[m]); ymb[q] = apply_gain<MODE>(B, nb[m]);
+    }
+    float2 a256, b256;
+    {
+        const float2 z = lds[256];                                // self-mirrored bin: A = 2 Re z, B = 2 Im z, both real
+        a256 = apply_gain<MODE>(make_float2(2.f * z.x, 0.f), na[256]);
+        b256 = apply_gain<MODE>(make_float2(2.f * z.y, 0.f), nb[256]);
+    }
+    // A frame with a non-finite bin (Wiener's 0/0 on an all-zero frame before any estimate, WF:204) has an all-NaN
+    // inverse transform in the reference.  Here it must not poison the frame it shares the transform with: its
+    // spectrum goes in as zero and its samples come out as NaN.
+    bool bad_a = false, bad_b = false;
+    if (MODE == 1) {
+        float ta = a256.x * 0.f, tb = b256.x * 0.f;               // NaN iff NaN or inf
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            ta += (yka[q].x + yka[q].y + yma[q].x + yma[q].y) * 0.f;
+            tb += (ykb[q].x + ykb[q].y + ymb[q].x + ymb[q].y) * 0.f;
+        }
+        bad_a = __ballot(ta != ta) != 0ull;
+        bad_b = __ballot(tb != tb) != 0ull;
+    }
+    float2 yk[4], ym[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const float2 ak = bad_a ? make_float2(0.f, 0.f) : yka[q], am = bad_a ? make_float2(0.f, 0.f) : yma[q];
+        const float2 bk = bad_b ? make_float2(0.f, 0.f) : ykb[q], bm = bad_b ? make_float2(0.f, 0.f) : ymb[q];
         yk[q] = cadd_pj(ak, bk);                                  // Ya[k] + j Yb[k]
         const float2 t = cadd_mj(am, bm);                         // conj(Ya) + j conj(Yb) = conj(Ya - j Yb)
         ym[q] = make_float2(t.x, -t.y);
     }
-    float2 y256;
-    {
-        const float2 z = lds[256];                                // self-mirrored bin: A = 2 Re z, B = 2 Im z, both real
-        const float2 a = apply_gain<MODE>(make_float2(2.f * z.x, 0.f), na[256]);
-        const float2 b = apply_gain<MODE>(make_float2(2.f * z.y, 0.f), nb[256]);
-        y256 = cadd_pj(a, b);
-    }
+    const float2 y256 = cadd_pj(bad_a ? make_float2(0.f, 0.f) : a256, bad_b ? make_float2(0.f, 0.f) : b256);
     wave_lds_fence();
 #pragma unroll
     for (int q = 0; q < 4; q++) {
@@ -889,7 +909,8 @@ __device__ __forceinline__ void dn512_pair(const float (&xa)[8], const float (&x
     wave_fft512<true>(y, lds, lane, tw);
     // the reference's 1/N after FFTW's unnormalised inverse (SS:248) with N = 512; a power of two, exact
 #pragma unroll
-    for (int d = 0; d < 8; d++) y[d] = make_float2(y[d].x * (1.0f / 512.0f), y[d].y * (1.0f / 512.0f));
+    for (int d = 0; d < 8; d++)
+        y[d] = make_float2(bad_a ? __builtin_nanf("") : y[d].x * (1.0f / 512.0f), bad_b ? __builtin_nanf("") : y[d].y * (1.0f / 512.0f));
     wave_lds_fence();
 }
 

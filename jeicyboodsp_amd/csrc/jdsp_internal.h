@@ -119,7 +119,7 @@ int launch_dft_direct_f64(hipStream_t stream, int kind, const void *in, double2 
 int launch_vad(hipStream_t s, const short *pcm, long n_blocks, const double *w_hi, int use_zcr, unsigned char *flags,
                long long *dbg_energy, int *dbg_zcr);
 int launch_vad256(hipStream_t s, const short *pcm, long n_blocks, const double *w_hi, unsigned char *flags,
-                  long long *dbg_energy, int *dbg_zcr);
+                  long long *dbg_energy, int *dbg_zcr, int use_zcr = 1);
 int launch_noise_estimate512(hipStream_t s, const short *pcm, long n_blocks, const DenoiseState *st_in,
                              DenoiseState *st_out, const int *events, const int *ev_n, const DenoisePlan *plan,
                              const float2 *table, const float *win512, float *mag, float *noise_rows);
@@ -197,6 +197,10 @@ int launch_mvdrn(hipStream_t s, const short *pcm, long chan_stride, int n_mics, 
                  const short *prev_in, short *prev_out, const int *events, const DenoisePlan *plan, const int *ver_base,
                  const unsigned long long *snap_mask, float2 *spec, const double2 *cov_in, double2 *cov_out,
                  const double2 *steer, double loading, float2 *weights, const float2 *table, short *out, float *precast);
+int launch_mvdrn512(hipStream_t s, const short *pcm, long chan_stride, int n_mics, long n_blocks, long calls_before,
+                    const short *prev_in, short *prev_out, const int *events, const DenoisePlan *plan, const int *ver_base,
+                    const unsigned long long *snap_mask, float2 *spec, const double2 *cov_in, double2 *cov_out,
+                    const double2 *steer, double loading, float2 *weights, const float2 *table, short *out, float *precast);
 // pitch_kernels.hip
 int launch_pitch(hipStream_t s, const short *pcm, long n_blocks, const short *prev_block, const float2 *table, int *arg,
                  float *rmax, float *autocorr);
@@ -315,6 +319,7 @@ struct jdsp_mvdr {
 struct jdsp_mvdrn {
     jdsp_ctx *ctx = nullptr;
     int n_mics = 0;
+    int n_fft = 1024, block = 512, n_bins = 513;   // FFT_PROCESSING_LEN, BLOCK_LEN, bins kept (1024 / 512 / 513 or 512 / 256 / 257)
     double loading = 0;
     long calls = 0;
     int cur = 0;

@@ -19,9 +19,17 @@ extern "C" {
 
 int jdsp_mvdrn_create(jdsp_ctx *ctx, int n_mics, const double *delays_s, double loading, jdsp_mvdrn **out)
 {
+    return jdsp_mvdrn_create_cfg(ctx, n_mics, delays_s, loading, 1024, out);
+}
+
+int jdsp_mvdrn_block_len(const jdsp_mvdrn *h) { return h ? h->block : 0; }
+
+int jdsp_mvdrn_create_cfg(jdsp_ctx *ctx, int n_mics, const double *delays_s, double loading, int n_fft, jdsp_mvdrn **out)
+{
     if (!ctx || !out) return JDSP_EINVAL;
     *out = nullptr;
     if (n_mics < 2 || n_mics > 8 || !(loading >= 0)) return fail(ctx, JDSP_EINVAL, "jdsp_mvdrn_create: 2 <= n_mics <= 8, loading >= 0");
+    if (n_fft != 1024 && n_fft != 512) return fail(ctx, JDSP_EINVAL, "jdsp_mvdrn_create_cfg: n_fft must be 1024 or 512");
     JDSP_HIP(ctx, hipSetDevice(ctx->device));
     int rc = jdsp::ensure_stft1024_table(ctx);
     if (rc) return rc;
@@ -30,15 +38,19 @@ int jdsp_mvdrn_create(jdsp_ctx *ctx, int n_mics, const double *delays_s, double 
     h->ctx = ctx;
     h->n_mics = n_mics;
     h->loading = loading;
+    h->n_fft = n_fft;
+    h->block = n_fft / 2;
+    h->n_bins = n_fft / 2 + 1;
+    const int nb = h->n_bins, keep = n_fft / 2 - 1;
     std::vector<double2> steer((size_t)513 * 8, make_double2(0.0, 0.0));
-    for (int k = 0; k < 513; k++)
+    for (int k = 0; k < nb; k++)
         for (int m = 0; m < n_mics; m++) {
             // the reference's steering phase (BeamForming_MVDR_ver1.cpp:164-165) per microphone delay
-            const double ang = 2 * 3.141592 * k * (16000.0 / 1024) * (delays_s ? delays_s[m] : 0.0);
+            const double ang = 2 * 3.141592 * k * (16000.0 / n_fft) * (delays_s ? delays_s[m] : 0.0);
             steer[(size_t)k * 8 + m] = make_double2(cos(ang), sin(ang));
         }
-    double w[512];
-    for (int i = 0; i < 512; i++) w[i] = (0.54 - 0.46 * cos(2 * 3.141592 * (511 + i) / (1024 - 1)));   // :217
+    double w[512] = {0};
+    for (int i = 0; i < h->block; i++) w[i] = (0.54 - 0.46 * cos(2 * 3.141592 * (keep + i) / (n_fft - 1)));   // :217
     hipError_t e = hipSuccess;
     for (int i = 0; i < 2 && e == hipSuccess; i++) {
         e = hipMalloc((void **)&h->cov[i], sizeof(double2) * 513 * 64);
@@ -115,8 +127,8 @@ static int mvdrn_reserve(jdsp_mvdrn *h, long n_blocks)
     if (e == hipSuccess) e = hipMalloc((void **)&h->ver_base, (n / 64 + 1) * sizeof(int));
     if (e == hipSuccess) e = hipMalloc((void **)&h->snap_mask, (n / 64 + 1) * sizeof(unsigned long long));
     // worst case: every block is an estimation frame -- one spectrum set and one weight set per block
-    if (e == hipSuccess) e = hipMalloc((void **)&h->spec, n * h->n_mics * 513 * sizeof(float2));
-    if (e == hipSuccess) e = hipMalloc((void **)&h->weights, (n + 1) * 513 * 8 * sizeof(float2));
+    if (e == hipSuccess) e = hipMalloc((void **)&h->spec, n * h->n_mics * (size_t)h->n_bins * sizeof(float2));
+    if (e == hipSuccess) e = hipMalloc((void **)&h->weights, (n + 1) * (size_t)h->n_bins * 8 * sizeof(float2));
     if (e != hipSuccess) {
         mvdrn_free_ws(h);
         return fail(ctx, JDSP_ENOMEM, "jdsp_mvdrn: workspace", e);
@@ -130,7 +142,7 @@ int jdsp_mvdrn_process_dev(jdsp_mvdrn *h, const int16_t *pcm_dev, long chan_stri
 {
     if (!h) return JDSP_EINVAL;
     jdsp_ctx *ctx = h->ctx;
-    if (n_blocks < 0 || chan_stride < n_blocks * 512) return fail(ctx, JDSP_EINVAL, "jdsp_mvdrn_process: bad sizes");
+    if (n_blocks < 0 || chan_stride < n_blocks * h->block) return fail(ctx, JDSP_EINVAL, "jdsp_mvdrn_process: bad sizes");
     const long n_out = jdsp_mvdrn_blocks_out(h, n_blocks);
     if (n_out_blocks) *n_out_blocks = n_out;
     if (n_blocks == 0) return JDSP_OK;
@@ -142,6 +154,18 @@ int jdsp_mvdrn_process_dev(jdsp_mvdrn *h, const int16_t *pcm_dev, long chan_stri
     if (rc) return rc;
     const int in = h->cur, ou = h->cur ^ 1;
     hipStream_t s = ctx->stream;
+    if (h->n_fft == 512) {
+        if (jdsp::launch_vad256(s, pcm_dev, n_blocks, h->w_vad, h->flags, nullptr, nullptr, 0) ||
+            jdsp::launch_run_plan(s, h->flags, n_blocks, h->run_len[in], h->run_len[ou], 0, h->ver_base, h->snap_mask,
+                                  h->events, h->ev_n, h->plan) ||
+            jdsp::launch_mvdrn512(s, pcm_dev, chan_stride, h->n_mics, n_blocks, h->calls, h->prev[in], h->prev[ou], h->events,
+                                  h->plan, h->ver_base, h->snap_mask, h->spec, h->cov[in], h->cov[ou], h->steer, h->loading,
+                                  h->weights, ctx->stft1024_table, out_dev, precast_dev))
+            return fail(ctx, JDSP_EHIP, "mvdrn512 launch", hipGetLastError());
+        h->cur ^= 1;
+        h->calls += n_blocks;
+        return JDSP_OK;
+    }
     if (jdsp::launch_vad(s, pcm_dev, n_blocks, h->w_vad, 0, h->flags, nullptr, nullptr) ||
         jdsp::launch_run_plan(s, h->flags, n_blocks, h->run_len[in], h->run_len[ou], 0, h->ver_base, h->snap_mask, h->events,
                               h->ev_n, h->plan) ||
@@ -159,14 +183,14 @@ int jdsp_mvdrn_process(jdsp_mvdrn *h, const int16_t *pcm_host, long chan_stride,
 {
     if (!h) return JDSP_EINVAL;
     jdsp_ctx *ctx = h->ctx;
-    if (n_blocks < 0 || chan_stride < n_blocks * 512) return fail(ctx, JDSP_EINVAL, "jdsp_mvdrn_process: bad sizes");
+    if (n_blocks < 0 || chan_stride < n_blocks * h->block) return fail(ctx, JDSP_EINVAL, "jdsp_mvdrn_process: bad sizes");
     const long n_out = jdsp_mvdrn_blocks_out(h, n_blocks);
     if (n_out_blocks) *n_out_blocks = n_out;
     if (n_blocks == 0) return JDSP_OK;
     if (!pcm_host || (n_out > 0 && !out_host)) return fail(ctx, JDSP_EINVAL, "jdsp_mvdrn_process: NULL buffer");
     JDSP_HIP(ctx, hipSetDevice(ctx->device));
-    const long stride_dev = n_blocks * 512;                    // repack the planes tightly (a multiple of 8)
-    const size_t in_b = (size_t)stride_dev * h->n_mics * 2, out_b = (size_t)(n_out > 0 ? n_out : 1) * 1024;
+    const long stride_dev = n_blocks * h->block;               // repack the planes tightly (a multiple of 8)
+    const size_t in_b = (size_t)stride_dev * h->n_mics * 2, out_b = (size_t)(n_out > 0 ? n_out : 1) * h->block * 2;
     int16_t *d_in = nullptr, *d_out = nullptr;
     float *d_pre = nullptr;
     hipError_t e = hipMalloc((void **)&d_in, in_b);
@@ -179,10 +203,10 @@ int jdsp_mvdrn_process(jdsp_mvdrn *h, const int16_t *pcm_host, long chan_stride,
                            hipMemcpyHostToDevice, s);
     if (e != hipSuccess) rc = fail(ctx, JDSP_EHIP, "jdsp_mvdrn_process: staging", e);
     if (!rc) rc = jdsp_mvdrn_process_dev(h, d_in, stride_dev, n_blocks, d_out, d_pre, nullptr);
-    if (!rc && n_out > 0 && (e = hipMemcpyAsync(out_host, d_out, (size_t)n_out * 1024, hipMemcpyDeviceToHost, s)) != hipSuccess)
+    if (!rc && n_out > 0 && (e = hipMemcpyAsync(out_host, d_out, (size_t)n_out * h->block * 2, hipMemcpyDeviceToHost, s)) != hipSuccess)
         rc = fail(ctx, JDSP_EHIP, "jdsp_mvdrn_process: D2H", e);
     if (!rc && n_out > 0 && precast_host &&
-        (e = hipMemcpyAsync(precast_host, d_pre, (size_t)n_out * 2048, hipMemcpyDeviceToHost, s)) != hipSuccess)
+        (e = hipMemcpyAsync(precast_host, d_pre, (size_t)n_out * h->block * 4, hipMemcpyDeviceToHost, s)) != hipSuccess)
         rc = fail(ctx, JDSP_EHIP, "jdsp_mvdrn_process: D2H", e);
     if ((e = hipStreamSynchronize(s)) != hipSuccess && !rc) rc = fail(ctx, JDSP_EHIP, "jdsp_mvdrn_process: sync", e);
     if (d_in) (void)hipFree(d_in);

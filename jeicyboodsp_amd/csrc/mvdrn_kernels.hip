@@ -93,8 +93,8 @@ __device__ __forceinline__ cd cd_shfl(cd a, int src) { return {__shfl(a.x, src),
 // One wave owns bin k; lane (r, c) = (lane >> 3, lane & 7) owns R_k[r][c].  After every event
 // the weights are recomputed: Gauss-Jordan on [R' | c] across the lanes (R' Hermitian positive
 // definite once loaded, so no pivoting), then w = x / (c^H x).  Version 0 = the matrix carried in.
-__global__ __launch_bounds__(64) void mvdrn_update_kernel(const float2 *__restrict__ spec, int n_mics,
-                                                          const DenoisePlan *__restrict__ plan,
+__global__ __launch_bounds__(64) void mvdrn_update_kernel(const float2 *__restrict__ spec, int n_mics, int n_bins,
+                                                          double inv_n, const DenoisePlan *__restrict__ plan,
                                                           const double2 *__restrict__ cov_in, double2 *__restrict__ cov_out,
                                                           const double2 *__restrict__ steer, double loading,
                                                           float2 *__restrict__ weights)
@@ -109,12 +109,12 @@ __global__ __launch_bounds__(64) void mvdrn_update_kernel(const float2 *__restri
     const int n_events = plan->n_events;
     for (int v = 0; v <= n_events; v++) {
         if (v > 0) {
-            const float2 *ev = spec + (size_t)(v - 1) * n_mics * kMvnBins + k;
-            const float2 xr = live ? ev[(size_t)r * kMvnBins] : make_float2(0.f, 0.f);
-            const float2 xc = live ? ev[(size_t)c * kMvnBins] : make_float2(0.f, 0.f);
-            // R[r][c] += X_r conj(X_c) / 1024
-            R.x += ((double)xr.x * xc.x + (double)xr.y * xc.y) * (1.0 / 1024.0);
-            R.y += ((double)xr.y * xc.x - (double)xr.x * xc.y) * (1.0 / 1024.0);
+            const float2 *ev = spec + (size_t)(v - 1) * n_mics * n_bins + k;
+            const float2 xr = live ? ev[(size_t)r * n_bins] : make_float2(0.f, 0.f);
+            const float2 xc = live ? ev[(size_t)c * n_bins] : make_float2(0.f, 0.f);
+            // R[r][c] += X_r conj(X_c) / N   (N = 1024 or 512: a power of two, exact)
+            R.x += ((double)xr.x * xc.x + (double)xr.y * xc.y) * inv_n;
+            R.y += ((double)xr.y * xc.x - (double)xr.x * xc.y) * inv_n;
         }
         double tr = 0.0;
         for (int d = 0; d < n_mics; d++) tr += __shfl(R.x, 9 * d);
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(64) void mvdrn_update_kernel(const float2 *__restri
         }
         const cd w = cd_mul(b, cd_inv(den));
         // [version][microphone][bin]: the apply kernel reads one microphone's weights for consecutive bins
-        if (c == 0 && r < n_mics) weights[((size_t)v * 8 + r) * kMvnBins + k] = make_float2((float)w.x, (float)w.y);
+        if (c == 0 && r < n_mics) weights[((size_t)v * 8 + r) * n_bins + k] = make_float2((float)w.x, (float)w.y);
     }
     cov_out[(size_t)k * 64 + lane] = make_double2(R.x, R.y);
 }
@@ -231,10 +231,227 @@ int launch_mvdrn(hipStream_t s, const short *pcm, long chan_stride, int n_mics, 
     const long g1 = n_blocks * n_mics < 4096 ? n_blocks * n_mics : 4096;
     hipLaunchKernelGGL(mvdrn_event_spectra_kernel, dim3((unsigned)g1), dim3(64), 0, s, pcm, chan_stride, n_mics, n_blocks,
                        prev_in, events, plan, table, spec);
-    hipLaunchKernelGGL(mvdrn_update_kernel, dim3(kMvnBins), dim3(64), 0, s, spec, n_mics, plan, cov_in, cov_out, steer,
-                       loading, weights);
+    hipLaunchKernelGGL(mvdrn_update_kernel, dim3(kMvnBins), dim3(64), 0, s, spec, n_mics, kMvnBins, 1.0 / 1024.0, plan, cov_in,
+                       cov_out, steer, loading, weights);
     const long grid = (n_blocks + 7) / 8 * 8;
     hipLaunchKernelGGL(mvdrn_apply_kernel, dim3((unsigned)grid), dim3(64), 0, s, pcm, chan_stride, n_mics, n_blocks,
+                       calls_before, prev_in, prev_out, ver_base, snap_mask, weights, table, out, precast);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// =======================================================================================
+// FFT_PROCESSING_LEN 512 (BASELINE config 5 as worded: "8-mic array, 512-pt STFT"): blocks of 256 samples, KEEP_LEN
+// 255, frames [first 255 samples of the previous block, block, 0], 257 bins, R_k += X X^H / 512, samples 255..510 out.
+// A 512-sample real frame is half a wave transform, so frames ride it in PAIRS (z = a + j b, see denoise512_kernel):
+// two MICROPHONES per forward transform, two consecutive BLOCKS per inverse transform.
+constexpr int kMvn512Bins = 257;
+
+// block j of one microphone, 256 samples: sample i; j == -1 is the previous call's last block, else silence
+__device__ __forceinline__ float mvn512_sample(const short *__restrict__ chan, long n_blocks,
+                                               const short *__restrict__ prev, long j, int i)
+{
+    if (j >= 0 && j < n_blocks) return (float)chan[j * 256 + i];
+    if (j == -1 && prev) return (float)prev[i];
+    return 0.f;
+}
+
+// Zh = FFT512(0.5 (a + j b)) as a natural-order image, then A[k], B[k] for this lane's bins k = lane + 64 q and 256
+__device__ __forceinline__ void mvn512_pair_spectra(const float (&xa)[8], const float (&xb)[8], const WaveTwiddles &tw,
+                                                    float2 *lds, int lane, float2 (&A)[5], float2 (&B)[5])
+{
+    float2 v[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) v[r] = make_float2(0.5f * xa[r], 0.5f * xb[r]);
+    wave_fft512<false>(v, lds, lane, tw);
+    store_natural_image(lds, lane, v);
+    wave_lds_fence();
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int k = lane + 64 * q;
+        const float2 zk = lds[k], zm = lds[512 - k];
+        A[q] = cadd_conj(zk, zm);
+        B[q] = csub_conj_mj(zk, zm);
+    }
+    const float2 z = lds[256];
+    A[4] = make_float2(2.f * z.x, 0.f);
+    B[4] = make_float2(2.f * z.y, 0.f);
+    wave_lds_fence();
+}
+
+// spec[(e * n_mics + m) * 257 + k] = X_m[k] of the frame [block j-1, block j], j = events[e]; microphones 2p, 2p+1 per wave
+__global__ __launch_bounds__(64) void mvdrn512_event_spectra_kernel(const short *__restrict__ pcm, long chan_stride,
+                                                                    int n_mics, long n_blocks,
+                                                                    const short *__restrict__ prev_all,
+                                                                    const int *__restrict__ events,
+                                                                    const DenoisePlan *__restrict__ plan,
+                                                                    const float2 *__restrict__ table,
+                                                                    float2 *__restrict__ spec)
+{
+    __shared__ __attribute__((aligned(16))) float2 lds[kWaveLdsComplex];
+    const int lane = threadIdx.x;
+    const int n_pairs = (n_mics + 1) >> 1;
+    const long total = (long)plan->n_events * n_pairs;
+    if ((long)blockIdx.x >= total) return;
+    WaveTwiddles tw;
+    load_wave_twiddles(tw, table, lane);
+    for (long w = blockIdx.x; w < total; w += gridDim.x) {
+        const int e = (int)(w / n_pairs), m0 = 2 * (int)(w % n_pairs), m1 = m0 + 1;
+        const long j = events[e];
+        float xa[8], xb[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const int pos = lane + 64 * r;                                   // 0..255: block j-1, 256..511: block j
+            const long jb = pos < 256 ? j - 1 : j;
+            const int i = pos & 255;
+            xa[r] = mvn512_sample(pcm + (size_t)m0 * chan_stride, n_blocks, prev_all + (size_t)m0 * 512, jb, i);
+            xb[r] = m1 < n_mics ? mvn512_sample(pcm + (size_t)m1 * chan_stride, n_blocks, prev_all + (size_t)m1 * 512, jb, i) : 0.f;
+        }
+        float2 A[5], B[5];
+        mvn512_pair_spectra(xa, xb, tw, lds, lane, A, B);
+        float2 *da = spec + ((size_t)e * n_mics + m0) * kMvn512Bins, *db = da + kMvn512Bins;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            da[lane + 64 * q] = A[q];
+            if (m1 < n_mics) db[lane + 64 * q] = B[q];
+        }
+        if (lane == 0) {
+            da[256] = A[4];
+            if (m1 < n_mics) db[256] = B[4];
+        }
+    }
+}
+
+// One wave = two consecutive blocks (j, j+1): per block ceil(n_mics / 2) forward transforms, Y_t[k] = sum_m conj(w_k[m]) X_m[k]
+// for k <= 256; then ONE inverse transform of Y_0 + j Y_1 (both Hermitian) gives the two output frames.
+__global__ __launch_bounds__(64) void mvdrn512_apply_kernel(const short *__restrict__ pcm, long chan_stride, int n_mics,
+                                                            long n_blocks, long calls_before,
+                                                            const short *__restrict__ prev_in, short *__restrict__ prev_out,
+                                                            const int *__restrict__ ver_base,
+                                                            const unsigned long long *__restrict__ snap_mask,
+                                                            const float2 *__restrict__ weights,
+                                                            const float2 *__restrict__ table, short *__restrict__ out,
+                                                            float *__restrict__ precast)
+{
+    __shared__ __attribute__((aligned(16))) float2 lds[kWaveLdsComplex];
+    const int lane = threadIdx.x;
+    const long per_xcd = (gridDim.x + 7) >> 3;
+    const long j0 = 2 * ((long)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3));
+    if (j0 >= n_blocks) return;
+    WaveTwiddles tw;
+    load_wave_twiddles(tw, table, lane);
+    float2 Y[2][5];
+#pragma unroll
+    for (int t = 0; t < 2; t++)
+#pragma unroll
+        for (int q = 0; q < 5; q++) Y[t][q] = make_float2(0.f, 0.f);
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        const long j = j0 + t;
+        if (j >= n_blocks) break;
+        const bool have_prev = calls_before + j > 0;
+        const float2 *W = weights + (size_t)version_of(ver_base, snap_mask, j) * kMvn512Bins * 8;
+        for (int m0 = 0; m0 < n_mics; m0 += 2) {
+            const int m1 = m0 + 1;
+            const short *ca = pcm + (size_t)m0 * chan_stride, *cb = pcm + (size_t)(m1 < n_mics ? m1 : m0) * chan_stride;
+            const short *pa = prev_in + (size_t)m0 * 512, *pb = prev_in + (size_t)(m1 < n_mics ? m1 : m0) * 512;
+            float xa[8], xb[8];
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const int pos = lane + 64 * r;        // frame position: < 255 previous block, 255..510 this block, 511 zero
+                float a = 0.f, b = 0.f;
+                if (pos < 255) {
+                    if (have_prev) { a = mvn512_sample(ca, n_blocks, pa, j - 1, pos); b = mvn512_sample(cb, n_blocks, pb, j - 1, pos); }
+                } else if (pos < 511) {
+                    a = (float)ca[j * 256 + pos - 255];
+                    b = (float)cb[j * 256 + pos - 255];
+                }
+                xa[r] = a;
+                xb[r] = m1 < n_mics ? b : 0.f;
+            }
+            float2 A[5], B[5];
+            mvn512_pair_spectra(xa, xb, tw, lds, lane, A, B);
+            const float2 *Wa = W + (size_t)m0 * kMvn512Bins, *Wb = W + (size_t)(m1 < n_mics ? m1 : m0) * kMvn512Bins;
+#pragma unroll
+            for (int q = 0; q < 5; q++) {
+                const int k = q < 4 ? lane + 64 * q : 256;
+                const float2 wa = Wa[k];
+                Y[t][q].x += wa.x * A[q].x + wa.y * A[q].y;                 // conj(w) X
+                Y[t][q].y += wa.x * A[q].y - wa.y * A[q].x;
+                if (m1 < n_mics) {
+                    const float2 wb = Wb[k];
+                    Y[t][q].x += wb.x * B[q].x + wb.y * B[q].y;
+                    Y[t][q].y += wb.x * B[q].y - wb.y * B[q].x;
+                }
+            }
+            if (j == n_blocks - 1) {                                         // the previous block of the next call
+#pragma unroll
+                for (int d = 0; d < 4; d++) {
+                    prev_out[(size_t)m0 * 512 + lane + 64 * d] = ca[j * 256 + lane + 64 * d];
+                    if (m1 < n_mics) prev_out[(size_t)m1 * 512 + lane + 64 * d] = cb[j * 256 + lane + 64 * d];
+                }
+            }
+        }
+    }
+    // A block whose weights are not finite (R_k singular: before enough estimation frames, like the reference's output
+    // before its first estimate) has a NaN spectrum and therefore an all-NaN frame -- but it must not poison the block
+    // it shares the inverse transform with: its spectrum goes in as zero and its samples come out as NaN.
+    bool bad[2];
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        float acc = 0.f;
+#pragma unroll
+        for (int q = 0; q < 5; q++) acc += Y[t][q].x * 0.f + Y[t][q].y * 0.f;       // NaN iff any part is NaN or inf
+        bad[t] = __ballot(acc != acc) != 0ull;
+        if (bad[t]) {
+#pragma unroll
+            for (int q = 0; q < 5; q++) Y[t][q] = make_float2(0.f, 0.f);
+        }
+    }
+    // packed inverse: bin k holds Y0 + j Y1, bin 512-k its Hermitian partner conj(Y0) + j conj(Y1) = conj(Y0 - j Y1)
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int k = lane + 64 * q;
+        const float2 m = cadd_mj(Y[0][q], Y[1][q]);
+        lds[512 - k] = make_float2(m.x, -m.y);                               // k = 0 lands in the spare slot 512
+        lds[k] = cadd_pj(Y[0][q], Y[1][q]);
+    }
+    if (lane == 0) lds[256] = cadd_pj(make_float2(Y[0][4].x, 0.f), make_float2(Y[1][4].x, 0.f));   // the Nyquist bin is real
+    wave_lds_fence();
+    float2 y[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) y[r] = lds[lane + 64 * r];
+    wave_lds_fence();
+    wave_fft512<true>(y, lds, lane, tw);
+    const long first_emit = calls_before >= 1 ? 0 : 1;
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        const long j = j0 + t;
+        if (j >= n_blocks || j < first_emit) continue;
+        short *o = out + (j - first_emit) * 256;
+        float *pc = precast ? precast + (j - first_emit) * 256 : nullptr;
+#pragma unroll
+        for (int d = 0; d < 8; d++) {
+            const int i = lane + 64 * d - 255;                               // samples 255..510 of the frame
+            const float sv = bad[t] ? __builtin_nanf("") : (t ? y[d].y : y[d].x) * (1.0f / 512.0f);
+            if (i >= 0 && i < 256) { o[i] = (short)cast_i16_bits(sv); if (pc) pc[i] = sv; }
+        }
+    }
+}
+
+int launch_mvdrn512(hipStream_t s, const short *pcm, long chan_stride, int n_mics, long n_blocks, long calls_before,
+                    const short *prev_in, short *prev_out, const int *events, const DenoisePlan *plan, const int *ver_base,
+                    const unsigned long long *snap_mask, float2 *spec, const double2 *cov_in, double2 *cov_out,
+                    const double2 *steer, double loading, float2 *weights, const float2 *table, short *out, float *precast)
+{
+    if (n_blocks <= 0) return 0;
+    const long work = n_blocks * ((n_mics + 1) / 2);
+    const long g1 = work < 4096 ? work : 4096;
+    hipLaunchKernelGGL(mvdrn512_event_spectra_kernel, dim3((unsigned)g1), dim3(64), 0, s, pcm, chan_stride, n_mics, n_blocks,
+                       prev_in, events, plan, table, spec);
+    hipLaunchKernelGGL(mvdrn_update_kernel, dim3(kMvn512Bins), dim3(64), 0, s, spec, n_mics, kMvn512Bins, 1.0 / 512.0, plan,
+                       cov_in, cov_out, steer, loading, weights);
+    const long grid = ((n_blocks + 1) / 2 + 7) / 8 * 8;
+    hipLaunchKernelGGL(mvdrn512_apply_kernel, dim3((unsigned)grid), dim3(64), 0, s, pcm, chan_stride, n_mics, n_blocks,
                        calls_before, prev_in, prev_out, ver_base, snap_mask, weights, table, out, precast);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }

@@ -59,8 +59,8 @@ class Engine:
     def fastconv(self, taps, n_fft):
         return FastConv(self, taps, n_fft)
 
-    def mvdr_multi(self, n_mics, delays=None, loading=0.0):
-        return MvdrMulti(self, n_mics, delays, loading)
+    def mvdr_multi(self, n_mics, delays=None, loading=0.0, n_fft=1024):
+        return MvdrMulti(self, n_mics, delays, loading, n_fft)
 
     def mvdr(self, d_time=0.0):
         return Mvdr(self, d_time)
@@ -711,16 +711,18 @@ class Mvdr:
 
 class MvdrMulti:
     """MVDR generalised to n_mics <= 8 with a per-bin covariance (jdsp_mvdrn, BASELINE config 5).
-    pcm: int16 [n_mics, n_blocks*512] (planar)."""
+    pcm: int16 [n_mics, n_blocks * block] (planar); block = n_fft / 2 (512, or 256 for 512-point frames)."""
 
-    def __init__(self, engine, n_mics, delays=None, loading=0.0):
+    def __init__(self, engine, n_mics, delays=None, loading=0.0, n_fft=1024):
         self.eng = engine
         self.n_mics = int(n_mics)
         d = np.ascontiguousarray(delays if delays is not None else np.zeros(n_mics), np.float64)
         assert d.size == n_mics
         h = C.c_void_p()
-        engine._ck(L.jdsp_mvdrn_create(engine._h, self.n_mics, d.ctypes.data_as(C.c_void_p), float(loading), C.byref(h)))
+        engine._ck(L.jdsp_mvdrn_create_cfg(engine._h, self.n_mics, d.ctypes.data_as(C.c_void_p), float(loading), int(n_fft),
+                                           C.byref(h)))
         self._h = h
+        self.block = L.jdsp_mvdrn_block_len(h)
         engine._children.append(self)
 
     def close(self):
@@ -743,27 +745,28 @@ class MvdrMulti:
         return L.jdsp_mvdrn_blocks_out(self._h, n_blocks)
 
     def process(self, pcm, want_precast=False):
+        B = self.block
         if _is_torch(pcm):
             import torch
             assert pcm.is_cuda and pcm.dtype == torch.int16 and pcm.is_contiguous() and pcm.dim() == 2
-            assert pcm.shape[0] == self.n_mics and pcm.shape[1] % 512 == 0
-            nb = pcm.shape[1] // 512
+            assert pcm.shape[0] == self.n_mics and pcm.shape[1] % B == 0
+            nb = pcm.shape[1] // B
             n_out = self.blocks_out(nb)
-            out = torch.empty(max(n_out, 1) * 512, dtype=torch.int16, device=pcm.device)
-            pre = torch.empty(max(n_out, 1) * 512, dtype=torch.float32, device=pcm.device) if want_precast else None
+            out = torch.empty(max(n_out, 1) * B, dtype=torch.int16, device=pcm.device)
+            pre = torch.empty(max(n_out, 1) * B, dtype=torch.float32, device=pcm.device) if want_precast else None
             self.eng._use_torch_stream()
             self.eng._ck(L.jdsp_mvdrn_process_dev(self._h, C.c_void_p(pcm.data_ptr()), pcm.shape[1], nb,
                                                   C.c_void_p(out.data_ptr()),
                                                   C.c_void_p(pre.data_ptr()) if want_precast else None, None))
-            out = out[:n_out * 512]
-            return (out, pre[:n_out * 512]) if want_precast else out
+            out = out[:n_out * B]
+            return (out, pre[:n_out * B]) if want_precast else out
         pcm = np.ascontiguousarray(pcm, np.int16)
-        assert pcm.ndim == 2 and pcm.shape[0] == self.n_mics and pcm.shape[1] % 512 == 0
-        nb = pcm.shape[1] // 512
+        assert pcm.ndim == 2 and pcm.shape[0] == self.n_mics and pcm.shape[1] % B == 0
+        nb = pcm.shape[1] // B
         n_out = self.blocks_out(nb)
-        out = np.zeros(max(n_out, 1) * 512, np.int16)
-        pre = np.zeros(max(n_out, 1) * 512, np.float32) if want_precast else None
+        out = np.zeros(max(n_out, 1) * B, np.int16)
+        pre = np.zeros(max(n_out, 1) * B, np.float32) if want_precast else None
         self.eng._ck(L.jdsp_mvdrn_process(self._h, pcm.ctypes.data_as(C.c_void_p), pcm.shape[1], nb,
                                           out.ctypes.data_as(C.c_void_p),
                                           pre.ctypes.data_as(C.c_void_p) if want_precast else None, None))
-        return (out[:n_out * 512], pre[:n_out * 512]) if want_precast else out[:n_out * 512]
+        return (out[:n_out * B], pre[:n_out * B]) if want_precast else out[:n_out * B]

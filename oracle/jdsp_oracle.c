@@ -714,32 +714,48 @@ static int solve_cplx(int n, double complex A[MVN_MAX][MVN_MAX], double complex 
     return 0;
 }
 
-long orc_mvdrn_stream(const short *pcm, long chan_stride, int n_mics, long n_blocks, const double *delays,
-                      double loading, short *out, double *pre_cast)
+/* the energy VAD of BeamForming_MVDR_ver1.cpp:207-242 on a frame of n samples [zeros(n/2 - 1), block(n/2), 0] */
+static int mvdr_vad_n(const short *block, int n)
 {
-    const int M = n_mics, NB = MV_N / 2 + 1;
-    orc_cplx *x = (orc_cplx *)calloc(MV_N, sizeof(orc_cplx));
-    orc_cplx *X = (orc_cplx *)calloc((size_t)M * MV_N, sizeof(orc_cplx));
-    orc_cplx *Y = (orc_cplx *)calloc(MV_N, sizeof(orc_cplx)), *y = (orc_cplx *)calloc(MV_N, sizeof(orc_cplx));
+    const int B = n / 2, K = n / 2 - 1;
+    double e = 0.0;
+    for (int i = 0; i < B; i++) {
+        int p = K + i;
+        short s = (short)(block[i] * (0.54 - 0.46 * cos(2 * PI_APPS * p / (n - 1))));      /* :217 */
+        e += pow(s, 2.0);                                                                   /* :221 */
+    }
+    e /= n;                                                                                 /* :229 */
+    return e > 700.0;                                                                       /* :233 */
+}
+
+long orc_mvdrn_stream2(const short *pcm, long chan_stride, int n_mics, long n_blocks, const double *delays,
+                       double loading, int n_fft, short *out, double *pre_cast)
+{
+    const int N = n_fft, B = n_fft / 2, K = n_fft / 2 - 1;       /* FFT_PROCESSING_LEN, BLOCK_LEN, KEEP_LEN (:38-40) */
+    const int M = n_mics, NB = N / 2 + 1;
+    if (N != 1024 && N != 512) return -1;
+    orc_cplx *x = (orc_cplx *)calloc(N, sizeof(orc_cplx));
+    orc_cplx *X = (orc_cplx *)calloc((size_t)M * N, sizeof(orc_cplx));
+    orc_cplx *Y = (orc_cplx *)calloc(N, sizeof(orc_cplx)), *y = (orc_cplx *)calloc(N, sizeof(orc_cplx));
     double complex *R = (double complex *)calloc((size_t)NB * M * M, sizeof(double complex));
     int iter = 0, count = 0;
     long n_out = 0;
     for (long b = 0; b < n_blocks; b++) {
-        const short *c0 = pcm + (size_t)b * MV_BLOCK;
-        if (!mvdr_vad(c0)) {
+        const short *c0 = pcm + (size_t)b * B;
+        if (!mvdr_vad_n(c0, N)) {
             iter++;
             if (iter > 1) {                       /* frame = [block b-1, block b] of every microphone */
                 for (int m = 0; m < M; m++) {
-                    const short *s = pcm + (size_t)m * chan_stride + (size_t)(b - 1) * MV_BLOCK;
-                    for (int i = 0; i < MV_N; i++) { x[i].re = s[i]; x[i].im = 0; }
-                    orc_dft_c2c(x, X + (size_t)m * MV_N, MV_N, -1);
+                    const short *s = pcm + (size_t)m * chan_stride + (size_t)(b - 1) * B;
+                    for (int i = 0; i < N; i++) { x[i].re = s[i]; x[i].im = 0; }
+                    orc_dft_c2c(x, X + (size_t)m * N, N, -1);
                 }
                 for (int k = 0; k < NB; k++)
                     for (int r = 0; r < M; r++)
                         for (int c = 0; c < M; c++) {
-                            double complex xr = X[(size_t)r * MV_N + k].re + I * X[(size_t)r * MV_N + k].im;
-                            double complex xc = X[(size_t)c * MV_N + k].re + I * X[(size_t)c * MV_N + k].im;
-                            R[((size_t)k * M + r) * M + c] += xr * conj(xc) / MV_N;
+                            double complex xr = X[(size_t)r * N + k].re + I * X[(size_t)r * N + k].im;
+                            double complex xc = X[(size_t)c * N + k].re + I * X[(size_t)c * N + k].im;
+                            R[((size_t)k * M + r) * M + c] += xr * conj(xc) / N;
                         }
             }
         } else {
@@ -747,11 +763,11 @@ long orc_mvdrn_stream(const short *pcm, long chan_stride, int n_mics, long n_blo
         }
         count++;
         for (int m = 0; m < M; m++) {
-            const short *s = pcm + (size_t)m * chan_stride + (size_t)b * MV_BLOCK;
-            memset(x, 0, sizeof(orc_cplx) * MV_N);
-            if (b > 0) for (int i = 0; i < MV_KEEP; i++) x[i].re = s[i - MV_BLOCK];     /* first 511 samples of block b-1 */
-            for (int i = 0; i < MV_BLOCK; i++) x[i + MV_KEEP].re = s[i];
-            orc_dft_c2c(x, X + (size_t)m * MV_N, MV_N, -1);
+            const short *s = pcm + (size_t)m * chan_stride + (size_t)b * B;
+            memset(x, 0, sizeof(orc_cplx) * N);
+            if (b > 0) for (int i = 0; i < K; i++) x[i].re = s[i - B];      /* first KEEP_LEN samples of block b-1 */
+            for (int i = 0; i < B; i++) x[i + K].re = s[i];
+            orc_dft_c2c(x, X + (size_t)m * N, N, -1);
         }
         for (int k = 0; k < NB; k++) {
             double complex A[MVN_MAX][MVN_MAX], cv[MVN_MAX], w[MVN_MAX];
@@ -760,7 +776,7 @@ long orc_mvdrn_stream(const short *pcm, long chan_stride, int n_mics, long n_blo
             for (int r = 0; r < M; r++) {
                 for (int c = 0; c < M; c++) A[r][c] = R[((size_t)k * M + r) * M + c];
                 A[r][r] += loading * tr / M;
-                double ang = 2 * PI_APPS * k * (16000.0 / MV_N) * (delays ? delays[r] : 0.0);
+                double ang = 2 * PI_APPS * k * (16000.0 / N) * (delays ? delays[r] : 0.0);
                 cv[r] = cos(ang) + I * sin(ang);
                 w[r] = cv[r];
             }
@@ -769,24 +785,30 @@ long orc_mvdrn_stream(const short *pcm, long chan_stride, int n_mics, long n_blo
             for (int r = 0; r < M; r++) den += conj(cv[r]) * w[r];
             double complex acc = 0;
             for (int r = 0; r < M; r++) {
-                double complex xr = X[(size_t)r * MV_N + k].re + I * X[(size_t)r * MV_N + k].im;
+                double complex xr = X[(size_t)r * N + k].re + I * X[(size_t)r * N + k].im;
                 acc += conj(w[r] / den) * xr;
             }
             Y[k].re = creal(acc); Y[k].im = cimag(acc);
-            if (k > 0 && k < MV_N / 2) { Y[MV_N - k].re = creal(acc); Y[MV_N - k].im = -cimag(acc); }
+            if (k > 0 && k < N / 2) { Y[N - k].re = creal(acc); Y[N - k].im = -cimag(acc); }
         }
-        orc_dft_c2c(Y, y, MV_N, +1);
+        orc_dft_c2c(Y, y, N, +1);
         if (count > 1) {
-            for (int i = 0; i < MV_BLOCK; i++) {
-                double v = y[i + MV_KEEP].re * 1. / MV_N;
-                out[(size_t)n_out * MV_BLOCK + i] = cast_i16(v);
-                if (pre_cast) pre_cast[(size_t)n_out * MV_BLOCK + i] = v;
+            for (int i = 0; i < B; i++) {
+                double v = y[i + K].re * 1. / N;
+                out[(size_t)n_out * B + i] = cast_i16(v);
+                if (pre_cast) pre_cast[(size_t)n_out * B + i] = v;
             }
             n_out++;
         }
     }
     free(x); free(X); free(Y); free(y); free(R);
     return n_out;
+}
+
+long orc_mvdrn_stream(const short *pcm, long chan_stride, int n_mics, long n_blocks, const double *delays,
+                      double loading, short *out, double *pre_cast)
+{
+    return orc_mvdrn_stream2(pcm, chan_stride, n_mics, n_blocks, delays, loading, 1024, out, pre_cast);
 }
 
 

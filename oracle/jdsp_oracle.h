@@ -154,6 +154,11 @@ int orc_mvdr_process_block(orc_mvdr *st, const short *left, const short *right, 
  * pcm: n_mics planes of chan_stride samples.  Returns blocks written. */
 long orc_mvdrn_stream(const short *pcm, long chan_stride, int n_mics, long n_blocks, const double *delays,
                       double loading, short *out, double *pre_cast);
+/* The same with FFT_PROCESSING_LEN = n_fft (1024 as above, or 512 = BASELINE config 5 as worded: blocks of 256,
+ * KEEP_LEN 255, frames [first 255 samples of the previous block, block, 0], R_k += X X^H / 512, samples 255..510
+ * emitted, f_k = k * 16000 / 512; thresholds unchanged). */
+long orc_mvdrn_stream2(const short *pcm, long chan_stride, int n_mics, long n_blocks, const double *delays,
+                       double loading, int n_fft, short *out, double *pre_cast);
 
 /* GMM scoring and the HMM recursion on MFCC vectors.
  * Both programs use Eigen only for one (1 x 12)(12 x 4) product per call (GMMAlgorithm_Test_Auto_ver2.cpp:228,

@@ -86,6 +86,9 @@ class Oracle:
         L.orc_mvdrn_stream.argtypes = [_c_short_p, C.c_long, C.c_int, C.c_long, _c_double_p, C.c_double, _c_short_p,
                                        _c_double_p]
         L.orc_mvdrn_stream.restype = C.c_long
+        L.orc_mvdrn_stream2.argtypes = [_c_short_p, C.c_long, C.c_int, C.c_long, _c_double_p, C.c_double, C.c_int,
+                                        _c_short_p, _c_double_p]
+        L.orc_mvdrn_stream2.restype = C.c_long
         L.orc_gmm_probability.argtypes = [_c_double_p, _c_double_p, _c_double_p, _c_double_p]
         L.orc_gmm_probability.restype = C.c_double
         L.orc_gmm_recognition.argtypes = [_c_double_p, C.c_long, C.c_void_p]
@@ -290,17 +293,18 @@ class Oracle:
         cat = lambda l, dt: np.concatenate(l) if l else np.zeros(0, dt)
         return cat(outs, np.int16), cat(pres, np.float64)
 
-    def mvdrn_stream(self, pcm, delays=None, loading=0.0):
-        """pcm: int16 [n_mics, n_samples] (planar)."""
+    def mvdrn_stream(self, pcm, delays=None, loading=0.0, n_fft=1024):
+        """pcm: int16 [n_mics, n_samples] (planar); blocks of n_fft / 2 samples."""
         pcm = np.ascontiguousarray(pcm, np.int16)
         m, n = pcm.shape
-        nb = n // 512
-        out = np.zeros(max(nb, 1) * 512, np.int16)
-        pre = np.zeros(max(nb, 1) * 512, np.float64)
+        B = n_fft // 2
+        nb = n // B
+        out = np.zeros(max(nb, 1) * B, np.int16)
+        pre = np.zeros(max(nb, 1) * B, np.float64)
         d = np.ascontiguousarray(delays if delays is not None else np.zeros(m), np.float64)
-        k = self.lib.orc_mvdrn_stream(_p(pcm, _c_short_p), n, m, nb, _p(d, _c_double_p), float(loading),
-                                      _p(out, _c_short_p), _p(pre, _c_double_p))
-        return out[:k * 512].copy(), pre[:k * 512].copy()
+        k = self.lib.orc_mvdrn_stream2(_p(pcm, _c_short_p), n, m, nb, _p(d, _c_double_p), float(loading), n_fft,
+                                       _p(out, _c_short_p), _p(pre, _c_double_p))
+        return out[:k * B].copy(), pre[:k * B].copy()
 
     def mfcc_native_cfg(self):
         c = MfccCfg()

@@ -261,3 +261,17 @@ def test_denoise_cfg_rejects_other_shapes(eng):
     with pytest.raises(jeicyboodsp_amd.JdspError):
         d.set_option("blocks_per_wave", 3)
     d.close()
+
+
+def test_wiener_512_point_zero_over_zero_stays_in_its_own_frame(eng, oracle):
+    """WF:204's 0/0 (an all-zero frame before any noise estimate) makes that frame's inverse transform NaN in the
+    reference, i.e. two output blocks; with two frames per transform the NaN frame must not leak into its partner."""
+    rng = np.random.default_rng(3)
+    pcm = np.clip(np.rint(rng.normal(0, 3000, 20 * 256)), -32768, 32767).astype(np.int16)
+    pcm[6 * 256:8 * 256] = 0                      # frame [block 6, block 7] is all zero
+    o_out, o_pre = oracle.denoise_stream(1, pcm, block=256)
+    assert 0 < (~np.isfinite(o_pre)).sum() <= 3 * 256
+    d = eng.denoiser(1, 512, 256)
+    out, pre = d.process(pcm, want_precast=True)
+    check_stream(out, pre, o_out, o_pre)
+    d.close()

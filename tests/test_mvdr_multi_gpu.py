@@ -80,3 +80,75 @@ def test_singular_until_enough_noise_frames_without_loading(eng, oracle):
     # that nothing crashes and the block count is right
     assert out.size == 23 * 512
     m.close()
+
+
+# ---- BASELINE config 5 as worded: 8-mic array on 512-point frames (blocks of 256, KEEP_LEN 255, 257 bins) ----------
+def array_scene256(seed, n_mics, n_blocks, src_delay=1, quiet=((0, 28), (60, 24))):
+    """The same scene cut into 256-sample blocks.  No reference counterpart: unpinned by construction, checked
+    against the build's own FP64 restatement (orc_mvdrn_stream2, n_fft = 512)."""
+    rng = np.random.default_rng(seed)
+    n = n_blocks * 256
+    src = rng.normal(0, 3000, n)
+    interf = rng.normal(0, 30, n)
+    pcm = np.stack([np.roll(src, src_delay * m) for m in range(n_mics)])
+    for b0, nb in quiet:
+        if b0 + nb <= n_blocks:
+            pcm[:, b0 * 256:(b0 + nb) * 256] = 0
+    pcm = pcm + rng.normal(0, 20, (n_mics, n)) + np.stack([np.roll(interf, -2 * m) for m in range(n_mics)])
+    return np.clip(np.rint(pcm), -32768, 32767).astype(np.int16), src, -src_delay * np.arange(n_mics) / 16000.0
+
+
+@pytest.mark.parametrize("n_mics,n_blocks", [(8, 100), (8, 1), (8, 2), (8, 3), (2, 61), (3, 100), (5, 77), (7, 100)])
+def test_512_point_frames_match_cpu_restatement(eng, oracle, n_mics, n_blocks):
+    """Two microphones per forward transform, two blocks per inverse transform: odd microphone counts leave the
+    last forward transform half empty, odd block counts the last inverse."""
+    pcm, _, delays = array_scene256(40 + n_mics, n_mics, n_blocks)
+    o_out, o_pre = oracle.mvdrn_stream(pcm, delays, 1e-3, n_fft=512)
+    m = eng.mvdr_multi(n_mics, delays, 1e-3, n_fft=512)
+    assert m.block == 256
+    out, pre = m.process(pcm, want_precast=True)
+    assert out.size == max(n_blocks - 1, 0) * 256
+    if out.size:
+        check(out, pre, o_out, o_pre)
+    else:
+        assert o_out.size == 0
+    m.close()
+
+
+def test_512_point_frames_chunked_device_calls_and_distortionless_response(eng, oracle):
+    import torch
+    pcm, src, delays = array_scene256(6, 8, 120)
+    o_out, o_pre = oracle.mvdrn_stream(pcm, delays, 1e-3, n_fft=512)
+    m = eng.mvdr_multi(8, delays, 1e-3, n_fft=512)
+    t = torch.from_numpy(pcm).cuda()
+    outs, pres, pos = [], [], 0
+    for n in [1, 3, 16, 33, 67]:                      # odd chunk sizes: the block pairs of a call never line up with the last call's
+        o, p = m.process(t[:, pos * 256:(pos + n) * 256].contiguous(), want_precast=True)
+        outs.append(o); pres.append(p); pos += n
+    torch.cuda.synchronize()
+    out = torch.cat(outs).cpu().numpy()
+    pre = torch.cat(pres).cpu().numpy()
+    check(out, pre, o_out, o_pre)
+    b = 100                                           # a loud block after both quiet stretches
+    got = pre[(b - 1) * 256:b * 256].astype(np.float64)
+    assert np.corrcoef(got, src[b * 256:(b + 1) * 256])[0, 1] > 0.99         # w^H c = 1: the steered source passes
+    m.close()
+
+
+def test_512_point_frames_singular_block_does_not_poison_its_pair(eng, oracle):
+    """Without loading the per-bin matrix is singular until n_mics estimation frames have been seen: those blocks are
+    NaN (-> 0 after the cast) like the reference's before its first estimate -- and ONLY those, although two blocks
+    share one inverse transform."""
+    pcm, _, delays = array_scene256(11, 2, 40, quiet=((5, 6),))      # blocks 1..5 have no estimate yet
+    o_out, o_pre = oracle.mvdrn_stream(pcm, delays, 0.0, n_fft=512)
+    m = eng.mvdr_multi(2, delays, 0.0, n_fft=512)
+    out, pre = m.process(pcm, want_precast=True)
+    assert not np.isfinite(o_pre[:256]).any() and np.isfinite(o_pre[-256:]).all()
+    check(out, pre, o_out, o_pre)
+    m.close()
+
+
+def test_mvdrn_cfg_rejects_other_frame_lengths(eng):
+    import jeicyboodsp_amd
+    with pytest.raises(jeicyboodsp_amd.JdspError):
+        eng.mvdr_multi(8, None, 0.0, n_fft=256)
