@@ -164,7 +164,10 @@ int jdsp_denoise_create_cfg(jdsp_ctx *ctx, int mode, int n_fft, int hop, jdsp_de
 int jdsp_denoise_block_len(const jdsp_denoise *h);
 int jdsp_denoise_destroy(jdsp_denoise *h);
 int jdsp_denoise_reset(jdsp_denoise *h);                       /* back to a fresh stream */
-int jdsp_denoise_set_option(jdsp_denoise *h, const char *name, long value);   /* "blocks_per_wave" */
+/* "blocks_per_wave": 0 (default: one round of resident waves walks the batch) or 1 / 2 / 4 / 8 (the compile-time
+ * variants, kept for A/B timing); "vad_trace": 1 keeps every block's energy sum and zero-crossing count for
+ * jdsp_denoise_vad_trace (a slower VAD kernel: two exact wave reductions per block); 0 (default) keeps the flags only. */
+int jdsp_denoise_set_option(jdsp_denoise *h, const char *name, long value);
 long jdsp_denoise_blocks_out(const jdsp_denoise *h, long n_blocks);
 /* Sizes the device workspace for batches of up to max_blocks (the only call
  * that allocates; process() calls it on demand). */
@@ -177,7 +180,8 @@ int jdsp_denoise_process(jdsp_denoise *h, const int16_t *pcm_host, long n_blocks
 int jdsp_denoise_noise(jdsp_denoise *h, double *noise_host);
 /* VoiceActivityDetection results of the first n blocks of the last process call:
  * voice flag, sum of squared truncated samples (dEnergy*1024, SS:135) and dZCR (SS:140).
- * Any pointer may be NULL.  Synchronises. */
+ * Any pointer may be NULL.  The flags are always there; energies and counts only when the "vad_trace" option was
+ * set before the call (JDSP_EINVAL otherwise).  Synchronises. */
 int jdsp_denoise_vad_trace(jdsp_denoise *h, long n, uint8_t *voice_host, int64_t *energy_sum_host,
                            int32_t *zcr_host);
 

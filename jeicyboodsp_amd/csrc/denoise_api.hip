@@ -109,6 +109,11 @@ int jdsp_denoise_reset(jdsp_denoise *h)
 int jdsp_denoise_set_option(jdsp_denoise *h, const char *name, long value)
 {
     if (!h || !name) return JDSP_EINVAL;
+    if (!strcmp(name, "vad_trace")) {
+        if (value != 0 && value != 1) return fail(h->ctx, JDSP_EINVAL, "jdsp_denoise_set_option: vad_trace must be 0 or 1");
+        h->opt_vad_trace = (int)value;
+        return JDSP_OK;
+    }
     if (!strcmp(name, "blocks_per_wave")) {
         if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8)
             return fail(h->ctx, JDSP_EINVAL, "jdsp_denoise_set_option: blocks_per_wave must be 0 (auto), 1, 2, 4 or 8");
@@ -183,7 +188,8 @@ int jdsp_denoise_process_dev(jdsp_denoise *h, const int16_t *pcm_dev, long n_blo
     jdsp::DenoiseState *st_out = h->st[h->cur ^ 1];
     hipStream_t s = ctx->stream;
     if (h->n_fft == 512) {
-        if (jdsp::launch_vad256(s, pcm_dev, n_blocks, h->w_hi256, h->flags, h->dbg_energy, h->dbg_zcr) ||
+        if (jdsp::launch_vad256(s, pcm_dev, n_blocks, h->w_hi256, h->flags, h->opt_vad_trace ? h->dbg_energy : nullptr,
+                                h->opt_vad_trace ? h->dbg_zcr : nullptr) ||
             jdsp::launch_denoise_plan(s, h->flags, n_blocks, st_in, st_out, h->ver_base, h->snap_mask, h->events, h->ev_n,
                                       h->plan) ||
             jdsp::launch_noise_estimate512(s, pcm_dev, n_blocks, st_in, st_out, h->events, h->ev_n, h->plan,
@@ -196,12 +202,13 @@ int jdsp_denoise_process_dev(jdsp_denoise *h, const int16_t *pcm_dev, long n_blo
         h->last_blocks = n_blocks;
         return JDSP_OK;
     }
-    if (jdsp::launch_vad(s, pcm_dev, n_blocks, h->w_hi, 1, h->flags, h->dbg_energy, h->dbg_zcr) ||
+    if (jdsp::launch_vad(s, pcm_dev, n_blocks, h->w_hi, 1, h->flags, h->opt_vad_trace ? h->dbg_energy : nullptr,
+                         h->opt_vad_trace ? h->dbg_zcr : nullptr) ||
         jdsp::launch_denoise_plan(s, h->flags, n_blocks, st_in, st_out, h->ver_base, h->snap_mask, h->events, h->ev_n,
                                   h->plan) ||
         jdsp::launch_noise_estimate(s, pcm_dev, n_blocks, st_in, st_out, h->events, h->ev_n, h->plan,
                                     ctx->stft1024_table, h->mag, h->rows) ||
-        jdsp::launch_denoise(s, h->mode, h->opt_k, pcm_dev, n_blocks, h->calls, st_in, st_out, h->ver_base,
+        jdsp::launch_denoise(s, h->mode, h->opt_k, ctx->n_cu, pcm_dev, n_blocks, h->calls, st_in, st_out, h->ver_base,
                              h->snap_mask, h->rows, ctx->stft1024_table, out_dev, precast_dev))
         return fail(ctx, JDSP_EHIP, "denoise launch", hipGetLastError());
     h->cur ^= 1;
@@ -277,7 +284,7 @@ int jdsp_denoise_apply(jdsp_denoise *h, const int16_t *pcm_host, long n_blocks, 
     if (e == hipSuccess) e = hipMemsetAsync(h->snap_mask, 0, ((size_t)n_blocks / 64 + 1) * sizeof(unsigned long long), s);
     if (e == hipSuccess) e = hipMemcpyAsync(st_out, st_in, sizeof(jdsp::DenoiseState), hipMemcpyDeviceToDevice, s);
     if (e != hipSuccess) rc = fail(ctx, JDSP_EHIP, "jdsp_denoise_apply: staging", e);
-    if (!rc && jdsp::launch_denoise(s, h->mode, h->opt_k, d_in, n_blocks, h->calls, st_in, st_out, h->ver_base,
+    if (!rc && jdsp::launch_denoise(s, h->mode, h->opt_k, ctx->n_cu, d_in, n_blocks, h->calls, st_in, st_out, h->ver_base,
                                     h->snap_mask, h->rows, ctx->stft1024_table, d_out, d_pre))
         rc = fail(ctx, JDSP_EHIP, "denoise launch", hipGetLastError());
     if (!rc && n_out > 0 && (e = hipMemcpyAsync(out_host, d_out, (size_t)n_out * 1024, hipMemcpyDeviceToHost, s)) != hipSuccess)
@@ -411,7 +418,7 @@ int jdsp_denoise_shard_finish_dev(jdsp_denoise *h, const float *last_all_dev, in
         sh.emit_from = lo - h->sh_ext0;
         sh.emit_to = h->sh_b1 - h->sh_ext0;
         // fresh state: the two halo blocks in front of the shard rebuild the overlap tail
-        if (jdsp::launch_denoise(s, h->mode, h->opt_k, h->sh_pcm, h->sh_b1 - h->sh_ext0, h->sh_ext0, h->st[h->cur],
+        if (jdsp::launch_denoise(s, h->mode, h->opt_k, ctx->n_cu, h->sh_pcm, h->sh_b1 - h->sh_ext0, h->sh_ext0, h->st[h->cur],
                                  h->st[h->cur ^ 1], h->ver_base, h->snap_mask, h->rows, ctx->stft1024_table, out_dev,
                                  precast_dev, &sh))
             return fail(ctx, JDSP_EHIP, "denoise launch", hipGetLastError());
@@ -435,6 +442,8 @@ int jdsp_denoise_vad_trace(jdsp_denoise *h, long n, uint8_t *voice_host, int64_t
     if (!h) return JDSP_EINVAL;
     jdsp_ctx *ctx = h->ctx;
     if (n < 0 || n > h->last_blocks) return fail(ctx, JDSP_EINVAL, "jdsp_denoise_vad_trace: n exceeds the last call");
+    if ((energy_sum_host || zcr_host) && !h->opt_vad_trace)
+        return fail(ctx, JDSP_EINVAL, "jdsp_denoise_vad_trace: energies / ZCR are kept only with set_option(\"vad_trace\", 1) before the call");
     if (n == 0) return JDSP_OK;
     if (voice_host) JDSP_HIP(ctx, hipMemcpyAsync(voice_host, h->flags, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
     if (energy_sum_host)

@@ -90,6 +90,73 @@ __global__ __launch_bounds__(64) void vad_kernel(const short *__restrict__ pcm, 
     }
 }
 
+// The same decision without the trace (dbg_energy / dbg_zcr are NULL in every batched chain): what costs in the
+// kernel above is not the arithmetic but the two wave reductions -- __shfl_xor is a ds_bpermute, 8.9 issue slots
+// each on this chip (tools/valu_rate.hip), eighteen of them per block.  Only the FLAG is needed here, so
+//   * the zero-crossing count never exists per lane: every sample position's comparison goes to an SGPR pair and
+//     the scalar unit counts its bits (s_bcnt1), beside the vector pipe;
+//   * a lane's energy is clamped to 2^20 per four samples before the wave sum: the sum then fits 32 bits, and it
+//     exceeds 700 * n exactly when the true sum does (a clamped lane alone is already above the threshold);
+//   * the one 32-bit wave sum is five DPP adds (quad swaps, row mirrors, row broadcasts) and a v_readlane.
+// Flags are bit-identical to the traced kernel's (tests/test_denoise_gpu.py compares both with the oracle).
+__device__ __forceinline__ unsigned int wave_sum_u32(unsigned int v)
+{
+    v += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true);     // quad_perm [1,0,3,2]
+    v += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, true);     // quad_perm [2,3,0,1]
+    v += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, true);    // row_half_mirror: sums of 8
+    v += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xf, 0xf, true);    // row_mirror: sums of 16
+    v += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, true);    // row_bcast15 into rows 1 and 3
+    v += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, true);    // row_bcast31 into rows 2 and 3
+    return (unsigned int)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+template <int SPL>
+__global__ __launch_bounds__(64) void vad_flags_kernel(const short *__restrict__ pcm, long n_blocks,
+                                                       const double *__restrict__ w_hi, int use_zcr,
+                                                       unsigned char *__restrict__ flags)
+{
+    static_assert(SPL == 8 || SPL == 4, "block of 512 or 256 samples");
+    const int lane = threadIdx.x;
+    const long b0 = (long)blockIdx.x * kVadBlocksPerWave;
+    if (b0 >= n_blocks) return;
+    double w[SPL];
+#pragma unroll
+    for (int k = 0; k < SPL; k++) w[k] = w_hi[SPL * lane + k];
+    u32x4 img[kVadBlocksPerWave];
+#pragma unroll
+    for (int i = 0; i < kVadBlocksPerWave; i++) {
+        const long b = b0 + i < n_blocks ? b0 + i : n_blocks - 1;
+        if (SPL == 8) {
+            img[i] = reinterpret_cast<const u32x4 *>(pcm + b * 512)[lane];
+        } else {
+            const uint2 h = reinterpret_cast<const uint2 *>(pcm + b * 256)[lane];
+            img[i].x = h.x; img[i].y = h.y; img[i].z = 0u; img[i].w = 0u;
+        }
+    }
+    unsigned int voice_bits = 0;                                   // wave-uniform
+#pragma unroll
+    for (int i = 0; i < kVadBlocksPerWave; i++) {
+        int x[9];
+        x[0] = (short)(img[i].x & 0xffffu); x[1] = (int)img[i].x >> 16;
+        x[2] = (short)(img[i].y & 0xffffu); x[3] = (int)img[i].y >> 16;
+        x[4] = (short)(img[i].z & 0xffffu); x[5] = (int)img[i].z >> 16;
+        x[6] = (short)(img[i].w & 0xffffu); x[7] = (int)img[i].w >> 16;
+        x[SPL] = __builtin_amdgcn_update_dpp(0, x[0], 0x130, 0xf, 0xf, true);    // wave_shl:1 -- lane i takes lane i+1; lane 63 gets 0
+        unsigned int qa = 0, qb = 0;
+        int z = 0;                                                  // wave-uniform: counted on the scalar unit
+#pragma unroll
+        for (int k = 0; k < SPL; k++) {
+            const int sv = (int)((double)x[k] * w[k]);              // (short)(short * double), in range
+            if (k < 4) qa += (unsigned int)__mul24(sv, sv); else qb += (unsigned int)__mul24(sv, sv);
+            z += __popcll(__ballot(__mul24(sv, x[k + 1]) < 0));
+        }
+        const unsigned int cap = 1u << 20;
+        const unsigned int e = wave_sum_u32((qa < cap ? qa : cap) + (qb < cap ? qb : cap));
+        if (e > 700u * 128u * SPL || (use_zcr && z < 200)) voice_bits |= 1u << i;
+    }
+    if (lane < kVadBlocksPerWave && b0 + lane < n_blocks) flags[b0 + lane] = (voice_bits >> lane) & 1u;
+}
+
 // ---------------------------------------------------------------------------------------
 // A13 bookkeeping.  One workgroup of 1024 threads; each thread owns 64 consecutive blocks,
 // whose voice flags it packs into one 64-bit mask, so every pass after the single load runs
@@ -433,6 +500,80 @@ __device__ __forceinline__ void denoise_frame(const unsigned int *raw, const Fra
     wave_lds_fence();
 }
 
+#ifndef JDSP_DENOISE_REGSPLIT
+#define JDSP_DENOISE_REGSPLIT 1       // 1: split / pre-split in registers (mirror operands by ds_bpermute); 0: LDS images
+#endif
+#if JDSP_DENOISE_REGSPLIT
+// The same frame with the bins kept in "lane + 64 d" registers from the forward transform to the inverse one:
+// no natural-order image, no Z' image, three fences fewer (frame_io.h).  noise[m] is read at m = lane + 64 d.
+template <int MODE>
+__device__ __forceinline__ void denoise_frame_reg(const unsigned int *raw, const FrameTables &t, const SplitTwiddles &sw,
+                                                  float2 *lds, int lane, const float *__restrict__ noise, float2 (&y)[8])
+{
+    float2 v[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const float2 s = unpack_i16x2(raw[r]);
+        v[r] = make_float2(s.x * t.win[r].x, s.y * t.win[r].y);
+    }
+    wave_fft512<false>(v, lds, lane, t.tw);
+    float2 zr[8], lo[8], hi[8];
+    mirror_fetch(v, lane, zr);
+    split_fwd_reg(v, zr, sw, lo, hi);
+#pragma unroll
+    for (int d = 0; d < 8; d++) {
+        const int m = lane + 64 * d;
+        lo[d] = apply_gain<MODE>(lo[d], noise[m]);
+        hi[d] = apply_gain<MODE>(hi[d], noise[m + 512]);
+        y[d] = presplit_inv_reg(lo[d], hi[d], sw.w[d]);
+    }
+    wave_lds_fence();                                            // the forward transform's last exchange reads are done
+    wave_fft512<true>(y, lds, lane, t.tw);
+    // the reference's 1/N after FFTW's unnormalised inverse (SS:248); a power of two, exact
+#pragma unroll
+    for (int d = 0; d < 8; d++) y[d] = make_float2(y[d].x * (1.0f / 1024.0f), y[d].y * (1.0f / 1024.0f));
+    wave_lds_fence();
+}
+#endif
+
+// The noise row of a frame held in registers: nlo[d] = N[lane + 64 d], nhi[d] = N[lane + 64 d + 512].  An estimate
+// changes at most every tenth block (SS:189) and usually far less often, so a wave walking a run of blocks reloads these
+// sixteen values only when the row pointer changes instead of fetching 4 KB per frame through L2.
+struct NoiseRegs { float lo[8], hi[8]; };
+__device__ __forceinline__ void load_noise_regs(NoiseRegs &n, const float *__restrict__ row, int lane)
+{
+#pragma unroll
+    for (int d = 0; d < 8; d++) { n.lo[d] = row[lane + 64 * d]; n.hi[d] = row[lane + 64 * d + 512]; }
+}
+
+template <int MODE>
+__device__ __forceinline__ void denoise_frame_nreg(const unsigned int *raw, const FrameTables &t, const SplitTwiddles &sw,
+                                                   float2 *lds, int lane, const NoiseRegs &n, float2 (&y)[8])
+{
+    float2 v[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const float2 s = unpack_i16x2(raw[r]);
+        v[r] = make_float2(s.x * t.win[r].x, s.y * t.win[r].y);
+    }
+    wave_fft512<false>(v, lds, lane, t.tw);
+    float2 zr[8], lo[8], hi[8];
+    mirror_fetch(v, lane, zr);
+    split_fwd_reg(v, zr, sw, lo, hi);
+#pragma unroll
+    for (int d = 0; d < 8; d++) {
+        lo[d] = apply_gain<MODE>(lo[d], n.lo[d]);
+        hi[d] = apply_gain<MODE>(hi[d], n.hi[d]);
+        y[d] = presplit_inv_reg(lo[d], hi[d], sw.w[d]);
+    }
+    wave_lds_fence();                                            // the forward transform's last exchange reads are done
+    wave_fft512<true>(y, lds, lane, t.tw);
+    // the reference's 1/N after FFTW's unnormalised inverse (SS:248); a power of two, exact
+#pragma unroll
+    for (int d = 0; d < 8; d++) y[d] = make_float2(y[d].x * (1.0f / 1024.0f), y[d].y * (1.0f / 1024.0f));
+    wave_lds_fence();
+}
+
 #ifndef JDSP_DENOISE_MINWAVES
 #define JDSP_DENOISE_MINWAVES 3
 #endif
@@ -468,6 +609,13 @@ __global__ __launch_bounds__(64, JDSP_DENOISE_MINWAVES) void denoise_kernel(
     for (int h = 0; h < K + 2; h++) load_block_pairs(pcm, n_blocks, st_in, j0 - 2 + h, lane, half[h]);
     FrameTables t;
     load_frame_tables(t, table, lane);
+#if JDSP_DENOISE_REGSPLIT
+    SplitTwiddles sw;
+    load_split_twiddles(sw, table, lane);
+#define JDSP_DN_FRAME(RAW, NOISE, Y) denoise_frame_reg<MODE>(RAW, t, sw, lds, lane, NOISE, Y)
+#else
+#define JDSP_DN_FRAME(RAW, NOISE, Y) denoise_frame<MODE>(RAW, t, lds, lane, NOISE, Y)
+#endif
 
     const long first_emit = sh.emit_from;                     // SS:260-263: calls 1 and 2 emit nothing
     unsigned int raw[8];
@@ -483,7 +631,7 @@ __global__ __launch_bounds__(64, JDSP_DENOISE_MINWAVES) void denoise_kernel(
 #pragma unroll
         for (int d = 0; d < 4; d++) tail[d] = make_float2(0.f, 0.f);
     } else {
-        denoise_frame<MODE>(raw, t, lds, lane, noise_row(noise_rows, ver_base, snap_mask, j0 - 1, sh), y);   // halo frame
+        JDSP_DN_FRAME(raw, noise_row(noise_rows, ver_base, snap_mask, j0 - 1, sh), y);   // halo frame
 #pragma unroll
         for (int d = 0; d < 4; d++) tail[d] = y[d + 4];
     }
@@ -498,7 +646,7 @@ __global__ __launch_bounds__(64, JDSP_DENOISE_MINWAVES) void denoise_kernel(
 #pragma unroll
             for (int d = 0; d < 8; d++) y[d] = make_float2(0.f, 0.f);
         } else {
-            denoise_frame<MODE>(raw, t, lds, lane, noise_row(noise_rows, ver_base, snap_mask, j, sh), y);
+            JDSP_DN_FRAME(raw, noise_row(noise_rows, ver_base, snap_mask, j, sh), y);
         }
         float2 o[4];
 #pragma unroll
@@ -520,6 +668,101 @@ __global__ __launch_bounds__(64, JDSP_DENOISE_MINWAVES) void denoise_kernel(
         if (j == n_blocks - 1) {
 #pragma unroll
             for (int r = 0; r < 4; r++) reinterpret_cast<unsigned int *>(st_out->prev)[lane + 64 * r] = half[i + 2][r];   // SS:257
+#pragma unroll
+            for (int d = 0; d < 4; d++) *reinterpret_cast<float2 *>(&st_out->tail[2 * lane + 128 * d]) = tail[d];
+        }
+    }
+}
+
+// The same work as denoise_kernel<MODE, K> with the run length chosen at launch instead of at compile time: one wave
+// walks `run` consecutive blocks (one recomputed halo frame in front), and the launch picks `run` so that the whole
+// batch is ONE round of resident waves (3 per SIMD at this register budget).  With K = 8 a 65,536-block batch is
+// 8,192 waves = 2.67 rounds of the 3,072 resident ones, i.e. 3 rounds of 9 frames = 27 frame times per wave slot for
+// 24 of work; with run = 22 it is 2,979 waves, one round, 23 frame times -- and the halo overhead falls from 1/8 to
+// 1/22.  A wave needs the next block's samples only one iteration later, so they are loaded at the top of the
+// iteration that precedes their use (4 dwords per lane) instead of all K + 2 blocks up front (40 VGPRs at K = 8).
+template <int MODE>
+__global__ __launch_bounds__(64, JDSP_DENOISE_MINWAVES) void denoise_run_kernel(
+    const short *__restrict__ pcm, long n_blocks, long calls_before, const DenoiseState *__restrict__ st_in,
+    DenoiseState *st_out, const int *__restrict__ ver_base, const unsigned long long *__restrict__ snap_mask,
+    const float *__restrict__ noise_rows, const float2 *__restrict__ table, short *__restrict__ out,
+    float *__restrict__ precast, DenoiseShard sh, int run)
+{
+    __shared__ __attribute__((aligned(16))) float2 lds[kWaveLdsComplex];
+    const int lane = threadIdx.x;
+    const long per_xcd = (gridDim.x + 7) >> 3;                // XCD-aware run order (speed only)
+    const long j0 = ((long)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3)) * run;
+    if (j0 >= n_blocks) return;
+    const long j1 = j0 + run < n_blocks ? j0 + run : n_blocks;
+
+    FrameTables t;
+    load_frame_tables(t, table, lane);
+    SplitTwiddles sw;
+    load_split_twiddles(sw, table, lane);
+
+    unsigned int raw[8], nxt[4];
+    float2 tail[4], y[8];
+    NoiseRegs nz;
+    const float *cur_row = nullptr;
+    load_block_pairs(pcm, n_blocks, st_in, j0 - 2, lane, nxt);
+#pragma unroll
+    for (int r = 0; r < 4; r++) raw[r] = nxt[r];
+    load_block_pairs(pcm, n_blocks, st_in, j0 - 1, lane, nxt);
+#pragma unroll
+    for (int r = 0; r < 4; r++) raw[r + 4] = nxt[r];
+    load_block_pairs(pcm, n_blocks, st_in, j0, lane, nxt);
+    if (j0 == 0) {
+        // rgsdOveraped[512..1023] carried over from the previous call
+#pragma unroll
+        for (int d = 0; d < 4; d++) tail[d] = *reinterpret_cast<const float2 *>(&st_in->tail[2 * lane + 128 * d]);
+    } else if (calls_before + j0 - 1 == 0) {
+        // the very first call of a stream only stashes its block (SS:211-216): no output, empty overlap
+#pragma unroll
+        for (int d = 0; d < 4; d++) tail[d] = make_float2(0.f, 0.f);
+    } else {
+        cur_row = noise_row(noise_rows, ver_base, snap_mask, j0 - 1, sh);
+        load_noise_regs(nz, cur_row, lane);
+        denoise_frame_nreg<MODE>(raw, t, sw, lds, lane, nz, y);   // halo frame
+#pragma unroll
+        for (int d = 0; d < 4; d++) tail[d] = y[d + 4];
+    }
+    const long first_emit = sh.emit_from;                     // SS:260-263: calls 1 and 2 emit nothing
+    for (long j = j0; j < j1; j++) {
+        unsigned int cur[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) { cur[r] = nxt[r]; raw[r] = raw[r + 4]; raw[r + 4] = nxt[r]; }
+        if (j + 1 < j1) load_block_pairs(pcm, n_blocks, st_in, j + 1, lane, nxt);      // needed one iteration from now
+        if (calls_before + j == 0) {
+#pragma unroll
+            for (int d = 0; d < 8; d++) y[d] = make_float2(0.f, 0.f);
+        } else {
+            const float *row = noise_row(noise_rows, ver_base, snap_mask, j, sh);
+            if (row != cur_row) {                                // wave-uniform: a new estimate was latched
+                cur_row = row;
+                load_noise_regs(nz, row, lane);
+            }
+            denoise_frame_nreg<MODE>(raw, t, sw, lds, lane, nz, y);
+        }
+        float2 o[4];
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+            o[d] = make_float2(tail[d].x + y[d].x, tail[d].y + y[d].y);      // SS:248 overlap-add
+            tail[d] = y[d + 4];                                               // SS:255-256
+        }
+        if (j >= first_emit && j < sh.emit_to) {
+            const long oi = j - first_emit;
+            unsigned int *dst = reinterpret_cast<unsigned int *>(out + oi * 512) + lane;
+#pragma unroll
+            for (int d = 0; d < 4; d++)                      // four coalesced 256-byte stores, in the layout as is
+                __builtin_nontemporal_store(cast_i16_bits(o[d].x) | (cast_i16_bits(o[d].y) << 16), dst + 64 * d);
+            if (precast) {
+#pragma unroll
+                for (int d = 0; d < 4; d++) *reinterpret_cast<float2 *>(precast + oi * 512 + 2 * lane + 128 * d) = o[d];
+            }
+        }
+        if (j == n_blocks - 1) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) reinterpret_cast<unsigned int *>(st_out->prev)[lane + 64 * r] = cur[r];   // SS:257
 #pragma unroll
             for (int d = 0; d < 4; d++) *reinterpret_cast<float2 *>(&st_out->tail[2 * lane + 128 * d]) = tail[d];
         }
@@ -667,9 +910,11 @@ int launch_vad(hipStream_t s, const short *pcm, long n_blocks, const double *w_h
                long long *dbg_energy, int *dbg_zcr)
 {
     if (n_blocks <= 0) return 0;
-    hipLaunchKernelGGL(vad_kernel<8>, dim3((unsigned)((n_blocks + kVadBlocksPerWave - 1) / kVadBlocksPerWave)), dim3(64), 0,
-                       s, pcm, n_blocks, w_hi, use_zcr, flags,
-                       dbg_energy, dbg_zcr);
+    const dim3 grid((unsigned)((n_blocks + kVadBlocksPerWave - 1) / kVadBlocksPerWave));
+    if (!dbg_energy && !dbg_zcr)
+        hipLaunchKernelGGL(vad_flags_kernel<8>, grid, dim3(64), 0, s, pcm, n_blocks, w_hi, use_zcr, flags);
+    else
+        hipLaunchKernelGGL(vad_kernel<8>, grid, dim3(64), 0, s, pcm, n_blocks, w_hi, use_zcr, flags, dbg_energy, dbg_zcr);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
@@ -678,8 +923,11 @@ int launch_vad256(hipStream_t s, const short *pcm, long n_blocks, const double *
                   long long *dbg_energy, int *dbg_zcr, int use_zcr)
 {
     if (n_blocks <= 0) return 0;
-    hipLaunchKernelGGL(vad_kernel<4>, dim3((unsigned)((n_blocks + kVadBlocksPerWave - 1) / kVadBlocksPerWave)), dim3(64), 0,
-                       s, pcm, n_blocks, w_hi, use_zcr, flags, dbg_energy, dbg_zcr);
+    const dim3 grid((unsigned)((n_blocks + kVadBlocksPerWave - 1) / kVadBlocksPerWave));
+    if (!dbg_energy && !dbg_zcr)
+        hipLaunchKernelGGL(vad_flags_kernel<4>, grid, dim3(64), 0, s, pcm, n_blocks, w_hi, use_zcr, flags);
+    else
+        hipLaunchKernelGGL(vad_kernel<4>, grid, dim3(64), 0, s, pcm, n_blocks, w_hi, use_zcr, flags, dbg_energy, dbg_zcr);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
@@ -725,7 +973,7 @@ static void launch_dn(hipStream_t s, const short *pcm, long n_blocks, long calls
                        st_in, st_out, ver_base, snap_mask, noise_rows, table, out, precast, sh);
 }
 
-int launch_denoise(hipStream_t s, int mode, int k_opt, const short *pcm, long n_blocks, long calls_before,
+int launch_denoise(hipStream_t s, int mode, int k_opt, int n_cu, const short *pcm, long n_blocks, long calls_before,
                    const DenoiseState *st_in, DenoiseState *st_out, const int *ver_base,
                    const unsigned long long *snap_mask, const float *noise_rows, const float2 *table, short *out,
                    float *precast, const DenoiseShard *shard)
@@ -738,6 +986,24 @@ int launch_denoise(hipStream_t s, int mode, int k_opt, const short *pcm, long n_
         sh.ver_row_off = nullptr;
         sh.emit_from = calls_before >= 2 ? 0 : 2 - calls_before;
         sh.emit_to = n_blocks;
+    }
+    if (k_opt == 0) {
+        // one round of resident waves: 3 per SIMD (JDSP_DENOISE_MINWAVES), 4 SIMDs per CU; never fewer than 4 blocks
+        // per wave (a quarter of halo overhead at most)
+        const long slots = (long)(n_cu > 0 ? n_cu : 256) * 4 * JDSP_DENOISE_MINWAVES;
+        long waves = (n_blocks + 3) / 4;
+        if (waves > slots) waves = slots;
+        long run = (n_blocks + waves - 1) / waves;
+        if (const char *e = getenv("JDSP_DENOISE_RUN")) run = atol(e) > 0 ? atol(e) : run;      // tuning only
+        waves = (n_blocks + run - 1) / run;
+        const long grid = (waves + 7) / 8 * 8;
+        if (mode == 0)
+            hipLaunchKernelGGL(denoise_run_kernel<0>, dim3((unsigned)grid), dim3(64), 0, s, pcm, n_blocks, calls_before, st_in,
+                               st_out, ver_base, snap_mask, noise_rows, table, out, precast, sh, (int)run);
+        else
+            hipLaunchKernelGGL(denoise_run_kernel<1>, dim3((unsigned)grid), dim3(64), 0, s, pcm, n_blocks, calls_before, st_in,
+                               st_out, ver_base, snap_mask, noise_rows, table, out, precast, sh, (int)run);
+        return hipGetLastError() == hipSuccess ? 0 : -1;
     }
 #define JDSP_DN(M, KK) launch_dn<M, KK>(s, pcm, n_blocks, calls_before, st_in, st_out, ver_base, snap_mask, noise_rows, table, out, precast, sh)
     if (mode == 0) {

@@ -78,6 +78,54 @@ __device__ __forceinline__ void load_mirror_pair(const float2 *img, int m, float
     zr0 = img[512 - m];
 }
 
+// ---- the split steps without an LDS image: "lane + 64 d" bins --------------------------------------------------
+// After wave_fft512 lane l holds Zh[l + 64 d] in v[d].  The split needs Zh[512 - m] next to Zh[m]: for m = l + 64 d
+// that is register 7 - d of lane 64 - l (lane 0: its own register 8 - d; Zh[512] = Zh[0]) -- one ds_bpermute per
+// dword, which moves data through the LDS crossbar without touching LDS memory.  Keeping the bins in this layout
+// (X[l + 64 d] and X[l + 64 d + 512] in lane l) means the per-bin work and the inverse pre-split are register-only
+// and Z'[l + 64 d] comes out exactly where the inverse transform takes its input: against the natural-order image
+// (write 4 KB, read 8 KB, then write and read Z' again) a frame moves 16 KB less through the LDS pipe, which is
+// these kernels' co-critical unit next to VALU issue.  Split twiddles: W^(l + 64 d), 8 per lane.
+struct SplitTwiddles { float2 w[8]; };
+
+__device__ __forceinline__ void load_split_twiddles(SplitTwiddles &t, const float2 *__restrict__ table, int lane);
+
+__device__ __forceinline__ void mirror_fetch(const float2 (&v)[8], int lane, float2 (&zr)[8])
+{
+    const int addr = ((64 - lane) & 63) << 2;
+#pragma unroll
+    for (int d = 0; d < 8; d++) {
+        const float2 src = v[7 - d];
+        float2 r;
+        r.x = __int_as_float(__builtin_amdgcn_ds_bpermute(addr, __float_as_int(src.x)));
+        r.y = __int_as_float(__builtin_amdgcn_ds_bpermute(addr, __float_as_int(src.y)));
+        const float2 own = v[(8 - d) & 7];                          // lane 0: 512 - 64 d = 64 (8 - d), its own register
+        zr[d] = lane == 0 ? own : r;
+    }
+}
+
+// X[m] = E + W^m O, X[m + 512] = E - W^m O for m = lane + 64 d (the 1/2 is folded into the window as everywhere)
+__device__ __forceinline__ void split_fwd_reg(const float2 (&v)[8], const float2 (&zr)[8], const SplitTwiddles &t,
+                                              float2 (&lo)[8], float2 (&hi)[8])
+{
+#pragma unroll
+    for (int d = 0; d < 8; d++) {
+        const float2 e = cadd_conj(v[d], zr[d]);
+        const float2 o = csub_conj_mj(v[d], zr[d]);
+        const float2 p = cmul(t.w[d], o);
+        lo[d] = cadd(e, p);
+        hi[d] = csub(e, p);
+    }
+}
+
+// Z'[m] = (Y[m] + Y[m+512]) + j (Y[m] - Y[m+512]) conj(W^m), m = lane + 64 d: the inverse transform's input, in place
+__device__ __forceinline__ float2 presplit_inv_reg(float2 ylo, float2 yhi, float2 w)
+{
+    const float2 s = cadd(ylo, yhi);
+    const float2 r = cmul_conj(csub(ylo, yhi), w);
+    return cadd_pj(s, r);
+}
+
 struct FrameTables {
     WaveTwiddles tw;
     float2 win[8];     // per lane: window pair of samples (2 lane + 128 r, +1), halved
@@ -91,6 +139,12 @@ __device__ __forceinline__ void load_frame_tables(FrameTables &t, const float2 *
     for (int r = 0; r < 8; r++) t.win[r] = table[kStftWin + lane + 64 * r];
     t.wsp[0] = table[kStftSplit + 2 * lane];
     t.wsp[1] = table[kStftSplit + 2 * lane + 1];
+}
+
+__device__ __forceinline__ void load_split_twiddles(SplitTwiddles &t, const float2 *__restrict__ table, int lane)
+{
+#pragma unroll
+    for (int d = 0; d < 8; d++) t.w[d] = table[kStftSplit + lane + 64 * d];
 }
 
 // Re-lays a half-frame out from the 16-byte-per-lane load image (lane holds samples

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdlib>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -136,7 +137,7 @@ int launch_denoise_plan(hipStream_t s, const unsigned char *flags, long n_blocks
 int launch_noise_estimate(hipStream_t s, const short *pcm, long n_blocks, const DenoiseState *st_in,
                           DenoiseState *st_out, const int *events, const int *ev_n, const DenoisePlan *plan,
                           const float2 *table, float *mag, float *noise_rows);
-int launch_denoise(hipStream_t s, int mode, int k_opt, const short *pcm, long n_blocks, long calls_before,
+int launch_denoise(hipStream_t s, int mode, int k_opt, int n_cu, const short *pcm, long n_blocks, long calls_before,
                    const DenoiseState *st_in, DenoiseState *st_out, const int *ver_base,
                    const unsigned long long *snap_mask, const float *noise_rows, const float2 *table, short *out,
                    float *precast, const DenoiseShard *shard = nullptr);
@@ -239,6 +240,7 @@ struct jdsp_denoise {
     float *mag = nullptr, *rows = nullptr;
     long last_blocks = 0;
     int opt_k = 0;
+    int opt_vad_trace = 0;                // 1: keep every block's energy sum and ZCR for jdsp_denoise_vad_trace (slower VAD kernel)
     int n_fft = 1024, block = 512;        // FFT_PROCESSING_SIZE, BLOCK_LEN = KEEP_LEN (SS:53-55); 512 / 256 also built
     double *w_hi256 = nullptr;            // 512-point frames: second half of the FP64 Hamming(512) (VAD)
     float *win512h = nullptr;             // 512-point frames: 0.5 * Hamming(512), natural order

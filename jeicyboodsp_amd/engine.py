@@ -312,7 +312,13 @@ class Denoiser:
         self.eng._ck(L.jdsp_denoise_noise(self._h, n.ctypes.data_as(C.c_void_p)))
         return n
 
-    def vad_trace(self, n):
+    def vad_trace(self, n, flags_only=False):
+        """(voice, energy sums, ZCR) of the last call's first n blocks; energies / ZCR need set_option("vad_trace", 1)
+        before that call (flags_only=True asks for the flags alone, which are always kept)."""
+        if flags_only:
+            v = np.zeros(n, np.uint8)
+            self.eng._ck(L.jdsp_denoise_vad_trace(self._h, n, v.ctypes.data_as(C.c_void_p), None, None))
+            return v
         v = np.zeros(n, np.uint8)
         e = np.zeros(n, np.int64)
         z = np.zeros(n, np.int32)

@@ -55,6 +55,7 @@ def test_denoise_stream_matches_oracle(eng, oracle, mode, n_blocks):
     pcm = speechlike(100 + n_blocks, n_blocks)
     o_out, o_pre, flags, noises, ver = oracle.denoise_trace(mode, pcm)
     d = eng.denoiser(mode)
+    d.set_option("vad_trace", 1)            # keep energies and ZCR: the traced VAD kernel
     out, pre = d.process(pcm, want_precast=True)
     check_stream(out, pre, o_out, o_pre)
     v, e, z = d.vad_trace(n_blocks)
@@ -72,7 +73,7 @@ def test_long_stream_crosses_plan_tiles(eng, oracle):
     d = eng.denoiser(1)
     out, pre = d.process(pcm, want_precast=True)
     check_stream(out, pre, o_out, o_pre)
-    v, _, _ = d.vad_trace(n_blocks)
+    v = d.vad_trace(n_blocks, flags_only=True)          # the flags-only VAD kernel
     assert np.array_equal(v.astype(np.int32), flags)
     assert noises.shape[0] > 100                       # many latches, on both sides of the tile boundary
     assert np.abs(d.noise() - noises[-1]).max() <= TOL * noises[-1].max()
@@ -82,6 +83,7 @@ def test_long_stream_crosses_plan_tiles(eng, oracle):
 def test_vad_energy_and_zcr_bit_exact(eng, oracle):
     pcm = speechlike(7, 64, pattern=[3, 2, 5, 1])
     d = eng.denoiser(0)
+    d.set_option("vad_trace", 1)            # keep energies and ZCR: the traced VAD kernel
     d.process(pcm)
     v, e, z = d.vad_trace(64)
     for b in range(64):
@@ -196,6 +198,7 @@ def test_denoise_512_point_frames_match_oracle(eng, oracle, mode, n_blocks):
     pcm = speechlike256(300 + n_blocks, n_blocks, pattern=[13, 5, 2, 3, 11, 4, 1, 1, 16, 14])
     o_out, o_pre, flags, noises, ver = oracle.denoise_trace(mode, pcm, block=256)
     d = eng.denoiser(mode, 512, 256)
+    d.set_option("vad_trace", 1)            # keep energies and ZCR: the traced VAD kernel
     assert d.block == 256
     out, pre = d.process(pcm, want_precast=True)
     check_stream(out, pre, o_out, o_pre)
@@ -247,7 +250,7 @@ def test_denoise_512_point_full_batch(eng, oracle):
     out, pre = d.process(torch.from_numpy(pcm).cuda(), want_precast=True)
     torch.cuda.synchronize()
     check_stream(out.cpu().numpy(), pre.cpu().numpy(), o_out, o_pre)
-    v, _, _ = d.vad_trace(n_blocks)
+    v = d.vad_trace(n_blocks, flags_only=True)          # the flags-only VAD kernel
     assert np.array_equal(v.astype(np.int32), flags) and noises.shape[0] > 100
     d.close()
 
@@ -274,4 +277,47 @@ def test_wiener_512_point_zero_over_zero_stays_in_its_own_frame(eng, oracle):
     d = eng.denoiser(1, 512, 256)
     out, pre = d.process(pcm, want_precast=True)
     check_stream(out, pre, o_out, o_pre)
+    d.close()
+
+
+@pytest.mark.parametrize("n_fft,block", [(1024, 512), (512, 256)])
+def test_flags_only_vad_equals_the_oracle_at_the_thresholds(eng, oracle, n_fft, block):
+    """The flags-only VAD kernel (clamped 32-bit energy sum by DPP, zero crossings counted on the scalar unit) must
+    make the reference's decision bit for bit: blocks whose energy straddles 700 and whose zero-crossing count
+    straddles 200, plus blocks with one huge sample (a lane's partial sum clamps) and all-zero blocks."""
+    rng = np.random.default_rng(123 + block)
+    n_blocks = 3000
+    x = np.zeros((n_blocks, block))
+    for b in range(n_blocks):
+        kind = b % 5
+        if kind == 0:                                   # energy near the threshold, white: ZCR ~ block / 2
+            x[b] = rng.normal(0, rng.uniform(40, 90), block)
+        elif kind == 1:                                 # smoothed noise: fewer zero crossings, loud enough to matter
+            w = rng.normal(0, 1, block + 8)
+            k = int(rng.integers(1, 4))
+            x[b] = np.convolve(w, np.ones(k) / k, mode="same")[:block] * rng.uniform(30, 120)
+        elif kind == 2:                                 # sign-alternating: ZCR near the maximum, quiet
+            x[b] = (np.abs(rng.normal(0, 30, block)) + rng.uniform(0, 20)) * np.where(np.arange(block) % 2 == 0, 1.0, -1.0)
+            flip = rng.integers(0, block, int(rng.integers(0, 120)))
+            x[b, flip] *= -1                            # knock the count down towards 200
+        elif kind == 3:                                 # one huge sample in silence
+            x[b, int(rng.integers(0, block))] = rng.choice([-32768, 32767, 20000])
+        # kind 4: all zeros
+    pcm = np.clip(np.rint(x), -32768, 32767).astype(np.int16).ravel()
+    want = np.array([oracle.vad_block(pcm[b * block:(b + 1) * block])[0] for b in range(n_blocks)], np.uint8)
+    assert 0.03 < want.mean() < 0.97                    # both decisions represented (256-sample blocks: ZCR < 200 says voice almost always)
+    d = eng.denoiser(0, n_fft, block)
+    d.process(pcm)
+    fast = d.vad_trace(n_blocks, flags_only=True)
+    assert np.array_equal(fast, want)
+    d.reset()
+    d.set_option("vad_trace", 1)
+    d.process(pcm)
+    traced, e, z = d.vad_trace(n_blocks)
+    assert np.array_equal(traced, want)
+    import jeicyboodsp_amd
+    d.set_option("vad_trace", 0)
+    d.process(pcm)
+    with pytest.raises(jeicyboodsp_amd.JdspError):
+        d.vad_trace(n_blocks)                           # energies / ZCR were not kept
     d.close()

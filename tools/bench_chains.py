@@ -68,6 +68,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--only", default="")
+    ap.add_argument("--denoise-k", type=int, default=0, help="denoise blocks_per_wave (0 = auto: one round of resident waves)")
     a = ap.parse_args()
     eng = jeicyboodsp_amd.Engine(0)
     orc = oracle_lib.load_oracle()
@@ -105,6 +106,7 @@ def main():
         t = torch.from_numpy(x).cuda()
         for mode, nm in ((0, "specsub"), (1, "wiener")):
             d = eng.denoiser(mode)
+            d.set_option("blocks_per_wave", a.denoise_k)
             d.process(t)                                        # sizes the workspace
 
             ms = timed(lambda: d.process(t), a.iters)           # steady state: one stream fed 65,536 blocks per call
