@@ -546,6 +546,9 @@ __device__ __forceinline__ void load_noise_regs(NoiseRegs &n, const float *__res
     for (int d = 0; d < 8; d++) { n.lo[d] = row[lane + 64 * d]; n.hi[d] = row[lane + 64 * d + 512]; }
 }
 
+#ifndef JDSP_DENOISE_MIRROR_LDS
+#define JDSP_DENOISE_MIRROR_LDS 1     // 1: mirror operands through a natural-order LDS image; 0: by ds_bpermute
+#endif
 template <int MODE>
 __device__ __forceinline__ void denoise_frame_nreg(const unsigned int *raw, const FrameTables &t, const SplitTwiddles &sw,
                                                    float2 *lds, int lane, const NoiseRegs &n, float2 (&y)[8])
@@ -558,13 +561,23 @@ __device__ __forceinline__ void denoise_frame_nreg(const unsigned int *raw, cons
     }
     wave_fft512<false>(v, lds, lane, t.tw);
     float2 zr[8], lo[8], hi[8];
+#if JDSP_DENOISE_MIRROR_LDS
+    wave_lds_fence();                                            // the transform's last exchange reads are done
+    mirror_fetch_lds(v, lds, lane, zr);
+#else
     mirror_fetch(v, lane, zr);
+#endif
     split_fwd_reg(v, zr, sw, lo, hi);
+    // (Tried: skipping the two X == 0 selects per bin of spectral subtraction unless a wave-wide test finds a zero
+    // bin -- a second copy of the gain loop behind a uniform branch.  134.6 us against 120.1 us per 65,536 blocks:
+    // the doubled loop body costs far more than the 32 selects it saves.  profiles/r02_denoise_ab.txt.)
+    {
 #pragma unroll
-    for (int d = 0; d < 8; d++) {
-        lo[d] = apply_gain<MODE>(lo[d], n.lo[d]);
-        hi[d] = apply_gain<MODE>(hi[d], n.hi[d]);
-        y[d] = presplit_inv_reg(lo[d], hi[d], sw.w[d]);
+        for (int d = 0; d < 8; d++) {
+            lo[d] = apply_gain<MODE>(lo[d], n.lo[d]);
+            hi[d] = apply_gain<MODE>(hi[d], n.hi[d]);
+            y[d] = presplit_inv_reg(lo[d], hi[d], sw.w[d]);
+        }
     }
     wave_lds_fence();                                            // the forward transform's last exchange reads are done
     wave_fft512<true>(y, lds, lane, t.tw);

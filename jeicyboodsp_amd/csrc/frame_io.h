@@ -104,6 +104,21 @@ __device__ __forceinline__ void mirror_fetch(const float2 (&v)[8], int lane, flo
     }
 }
 
+// The same operands through a natural-order LDS image instead: 8 ds_write_b64 + 8 ds_read_b64 (lane l reads slot
+// 512 - l - 64 d: consecutive lanes, consecutive slots, conflict-free; slot 512 = slot 0, so lane 0 needs no special
+// case).  A ds_bpermute_b32 costs the LDS pipe three times a ds_read_b64's worth per byte (tools/valu_rate.hip: 8.9
+// issue slots against 16 x 1.6 for the selects it also needs), so this is the cheaper way to fetch the mirror --
+// what is saved against the round-1 image is its second read (Zh[m] stays in registers) and the whole Z' image.
+// `img` must not be in use: fence before this if the transform's last exchange may still be reading it.
+__device__ __forceinline__ void mirror_fetch_lds(const float2 (&v)[8], float2 *img, int lane, float2 (&zr)[8])
+{
+    store_natural_image(img, lane, v);
+    wave_lds_fence();
+#pragma unroll
+    for (int d = 0; d < 8; d++) zr[d] = img[512 - lane - 64 * d];
+    wave_lds_fence();
+}
+
 // X[m] = E + W^m O, X[m + 512] = E - W^m O for m = lane + 64 d (the 1/2 is folded into the window as everywhere)
 __device__ __forceinline__ void split_fwd_reg(const float2 (&v)[8], const float2 (&zr)[8], const SplitTwiddles &t,
                                               float2 (&lo)[8], float2 (&hi)[8])

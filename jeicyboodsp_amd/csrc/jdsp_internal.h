@@ -82,6 +82,7 @@ struct MfccDev {
     // (at most 16, all with rgdFiBins value seg[L].z) with weights seg_w[t * 64 + L]; seg_ok = it fits 64 lanes
     const int4 *seg;
     const float *seg_w;
+    const float *seg_c;          // 1 - seg_w inside a piece, 0 past its last bin
     int seg_ok;
     const double *dct;           // [n_chan][32]: sqrt(2/C) cos(PI i (k-0.5)/C)
     const double *lifter_w;      // [32]: 1 + L/2 sin(PI i / L)

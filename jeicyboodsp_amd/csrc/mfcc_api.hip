@@ -59,7 +59,7 @@ int jdsp_mfcc_create(jdsp_ctx *ctx, const jdsp_mfcc_cfg *cfg, jdsp_mfcc **out)
     // ---- the same filterbank by channel index: every run of bins with one rgdFiBins value, cut into pieces of
     // at most 16 bins, one piece per lane (the index never decreases with the bin, :131-137) ----
     std::vector<int> seg(64 * 4, 0);
-    std::vector<float> seg_w(16 * 64, 0.f);
+    std::vector<float> seg_w(16 * 64, 0.f), seg_c(16 * 64, 0.f);
     int seg_lanes = 0;
     bool seg_ok = true;
     for (int i = 0; i < NB && seg_ok;) {
@@ -69,7 +69,10 @@ int jdsp_mfcc_create(jdsp_ctx *ctx, const jdsp_mfcc_cfg *cfg, jdsp_mfcc **out)
             if (seg_lanes == 64) { seg_ok = false; break; }
             const int cnt = e - s0 < 16 ? e - s0 : 16;
             seg[4 * seg_lanes + 0] = s0; seg[4 * seg_lanes + 1] = cnt; seg[4 * seg_lanes + 2] = h->fi_bins[i];
-            for (int t = 0; t < cnt; t++) seg_w[(size_t)t * 64 + seg_lanes] = (float)h->fbank[s0 + t];
+            for (int t = 0; t < cnt; t++) {
+                seg_w[(size_t)t * 64 + seg_lanes] = (float)h->fbank[s0 + t];
+                seg_c[(size_t)t * 64 + seg_lanes] = (float)(1.0 - h->fbank[s0 + t]);             // (1 - rgdFilterBank[i]), :161,:165
+            }
             seg_lanes++;
         }
         i = e;
@@ -91,7 +94,7 @@ int jdsp_mfcc_create(jdsp_ctx *ctx, const jdsp_mfcc_cfg *cfg, jdsp_mfcc **out)
     const size_t o_win = 0, o_fb = o_win + sizeof(float2) * 512, o_k = o_fb + 512 * sizeof(float),
                  o_dct = o_k + 512 * sizeof(int), o_lift = o_dct + dct.size() * sizeof(double),
                  o_seg = o_lift + 32 * sizeof(double), o_segw = o_seg + seg.size() * sizeof(int),
-                 total = o_segw + seg_w.size() * sizeof(float);
+                 o_segc = o_segw + seg_w.size() * sizeof(float), total = o_segc + seg_c.size() * sizeof(float);
     std::vector<char> host(total, 0);
     memcpy(&host[o_win], window.data(), sizeof(float2) * 512);
     memcpy(&host[o_fb], mel_fb.data(), 512 * sizeof(float));
@@ -100,6 +103,7 @@ int jdsp_mfcc_create(jdsp_ctx *ctx, const jdsp_mfcc_cfg *cfg, jdsp_mfcc **out)
     memcpy(&host[o_lift], lift.data(), 32 * sizeof(double));
     memcpy(&host[o_seg], seg.data(), seg.size() * sizeof(int));
     memcpy(&host[o_segw], seg_w.data(), seg_w.size() * sizeof(float));
+    memcpy(&host[o_segc], seg_c.data(), seg_c.size() * sizeof(float));
     hipError_t e = hipMalloc(&h->blob, total);
     if (e == hipSuccess) e = hipMemcpy(h->blob, host.data(), total, hipMemcpyHostToDevice);
     if (e != hipSuccess) {
@@ -116,6 +120,7 @@ int jdsp_mfcc_create(jdsp_ctx *ctx, const jdsp_mfcc_cfg *cfg, jdsp_mfcc **out)
     h->dev.mel_k = (const int *)(b + o_k);
     h->dev.seg = (const int4 *)(b + o_seg);
     h->dev.seg_w = (const float *)(b + o_segw);
+    h->dev.seg_c = (const float *)(b + o_segc);
     h->dev.seg_ok = seg_ok ? 1 : 0;
     h->dev.dct = (const double *)(b + o_dct);
     h->dev.lifter_w = (const double *)(b + o_lift);

@@ -222,6 +222,23 @@ __device__ __forceinline__ void mfcc_mel(const float *mag, float *logmel, const 
     if (cur < p.n_chan) atomicAdd(&logmel[cur], hi);
 }
 
+// a + a[lane ^ 16] / a + a[lane ^ 32] for a double: the swap leaves {even-row value, odd-row value} (resp. {lower-half,
+// upper-half}) of the pair in the two results on both lanes of the pair, so their sum is the same bit pattern on both
+__device__ __forceinline__ double sum_xor16_f64(double a)
+{
+    const int lo = __double2loint(a), hi = __double2hiint(a);
+    const auto l = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const auto h = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    return __hiloint2double(h[0], l[0]) + __hiloint2double(h[1], l[1]);
+}
+__device__ __forceinline__ double sum_xor32_f64(double a)
+{
+    const int lo = __double2loint(a), hi = __double2hiint(a);
+    const auto l = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const auto h = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return __hiloint2double(h[0], l[0]) + __hiloint2double(h[1], l[1]);
+}
+
 __global__ __launch_bounds__(64) void mfcc_x2_kernel(const short *__restrict__ pcm, const long long *__restrict__ starts,
                                                      long n_frames, MfccDev p, const float2 *__restrict__ table,
                                                      double *__restrict__ feats)
@@ -241,11 +258,14 @@ __global__ __launch_bounds__(64) void mfcc_x2_kernel(const short *__restrict__ p
     load_wave_twiddles(tw, table, lane);
     const float2 wsp0 = table[kStftSplit + 2 * lane];
     const float2 wsp1 = table[kStftSplit + 2 * lane + 1];
-    // this lane's piece of the filterbank: bins [sg.x, sg.x + sg.y) of channel index sg.z, weights sw[t]
+    // this lane's piece of the filterbank: bins [sg.x, sg.x + sg.y) of channel index sg.z, weights sw[t] towards
+    // channel sg.z - 1 and cw[t] = 1 - sw[t] towards channel sg.z; both are ZERO past the piece's last bin, so the
+    // sixteen steps below need neither a branch nor a select (the branchy form compiled to 94 exec-mask regions
+    // with a dependent LDS read and an s_waitcnt in each: the kernel spent 65 % of its wave cycles waiting)
     const int4 sg = p.seg[lane];
-    float sw[16];
+    float sw[16], cw[16];
 #pragma unroll
-    for (int t = 0; t < 16; t++) sw[t] = p.seg_w[t * 64 + lane];
+    for (int t = 0; t < 16; t++) { sw[t] = p.seg_w[t * 64 + lane]; cw[t] = p.seg_c[t * 64 + lane]; }
 
     wave_fft512_x2<false>(va, vb, lds[0], lds[1], lane, tw);
     store_natural_image(lds[0], lane, va);
@@ -258,15 +278,20 @@ __global__ __launch_bounds__(64) void mfcc_x2_kernel(const short *__restrict__ p
     mfcc_magnitudes(lds[1], lane, wsp0, wsp1, amp_b);
     wave_lds_fence();                                                // every lane's split reads are done: overwrite
     float *mag_a = reinterpret_cast<float *>(lds[0]), *mag_b = reinterpret_cast<float *>(lds[1]);
+    // |X| is stored PADDED, bin i at i + (i >> 4): the filterbank below reads it one piece per lane, and the pieces
+    // of the wide upper channels start 16 bins apart -- unpadded, those lanes' addresses are 16 words apart and fall
+    // on two banks (the counter pass showed the LDS pipe busy 72 % of the kernel, 18 % of it bank conflicts)
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const int m = 128 * j + 2 * lane;
         if (p.bin_stride == 1) {
-            *reinterpret_cast<float2 *>(&mag_a[m]) = amp_a[j];
-            *reinterpret_cast<float2 *>(&mag_b[m]) = amp_b[j];
+            const int q = m + (m >> 4);                              // m even: m and m + 1 share a group of 16
+            mag_a[q] = amp_a[j].x; mag_a[q + 1] = amp_a[j].y;
+            mag_b[q] = amp_b[j].x; mag_b[q + 1] = amp_b[j].y;
         } else {                                                     // 512-point bins = even 1024-point bins
-            mag_a[m >> 1] = amp_a[j].x;
-            mag_b[m >> 1] = amp_b[j].x;
+            const int h = m >> 1, q = h + (h >> 4);
+            mag_a[q] = amp_a[j].x;
+            mag_b[q] = amp_b[j].x;
         }
     }
     wave_lds_fence();
@@ -276,13 +301,18 @@ __global__ __launch_bounds__(64) void mfcc_x2_kernel(const short *__restrict__ p
     // atomic instructions per frame, ~32 LDS cycles each: the LDS pipe was busy 72 % of the kernel.)
     {
         float lo_a = 0.f, hi_a = 0.f, lo_b = 0.f, hi_b = 0.f;
+        float ma[16], mb[16];
+#pragma unroll
+        for (int t = 0; t < 16; t++) {                               // all thirty-two reads in flight together
+            const int bin = min(sg.x + t, 511);                      // past the piece: any finite value, its weights are 0
+            const int q = bin + (bin >> 4);
+            ma[t] = mag_a[q];
+            mb[t] = mag_b[q];
+        }
 #pragma unroll
         for (int t = 0; t < 16; t++) {
-            const bool on = t < sg.y;
-            const int bin = on ? sg.x + t : 0;
-            const float ma = on ? mag_a[bin] : 0.f, mb = on ? mag_b[bin] : 0.f;
-            lo_a = fmaf(sw[t], ma, lo_a); hi_a += fmaf(-sw[t], ma, ma);       // :164 / :161,:165-166
-            lo_b = fmaf(sw[t], mb, lo_b); hi_b += fmaf(-sw[t], mb, mb);
+            lo_a = fmaf(sw[t], ma[t], lo_a); hi_a = fmaf(cw[t], ma[t], hi_a);   // :164 / :161,:165-166
+            lo_b = fmaf(sw[t], mb[t], lo_b); hi_b = fmaf(cw[t], mb[t], hi_b);
         }
         if (sg.y > 0) {
             if (sg.z >= 1) { atomicAdd(&logmel[0][sg.z - 1], lo_a); atomicAdd(&logmel[1][sg.z - 1], lo_b); }
@@ -291,8 +321,10 @@ __global__ __launch_bounds__(64) void mfcc_x2_kernel(const short *__restrict__ p
     }
     wave_lds_fence();
     if (lane < p.n_chan) {
-        logmel[0][lane] = logf(logmel[0][lane]);                     // :171
-        logmel[1][lane] = logf(logmel[1][lane]);
+        // :171.  Hardware log2 times ln 2 (1 ulp of the FP32 logarithm; logf() is ~25 instructions of range fix-up
+        // per value for the last half ulp, of which nothing survives the 1e-5 bar); ln 0 = -inf as in the reference
+        logmel[0][lane] = __logf(logmel[0][lane]);
+        logmel[1][lane] = __logf(logmel[1][lane]);
     }
     wave_lds_fence();
     // DCT-II (:178-182) and lifter (:189), both frames off one pass over the table
@@ -308,9 +340,10 @@ __global__ __launch_bounds__(64) void mfcc_x2_kernel(const short *__restrict__ p
                 acc_b += c * (double)logmel[1][k];
             }
         }
-        const double oa = __shfl_xor(acc_a, 16), ob = __shfl_xor(acc_b, 16);
-        if (!wide) { acc_a += oa; acc_b += ob; }
-        acc_a += __shfl_xor(acc_a, 32); acc_b += __shfl_xor(acc_b, 32);
+        // lane ^ 16 and lane ^ 32 partners by v_permlane16/32_swap (one VALU instruction per dword; a __shfl_xor is
+        // a ds_bpermute, 8.9 issue slots each on this chip: tools/valu_rate.hip)
+        if (!wide) { acc_a = sum_xor16_f64(acc_a); acc_b = sum_xor16_f64(acc_b); }
+        acc_a = sum_xor32_f64(acc_a); acc_b = sum_xor32_f64(acc_b);
         if (lane < p.n_cep) {
             const double lw = p.lifter_w[lane];
             feats[fa * p.n_cep + lane] = acc_a * lw;

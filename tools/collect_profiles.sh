@@ -1,8 +1,8 @@
 #!/bin/bash
 # Runs on the GPU box (gpurun -- bash tools/collect_profiles.sh): the full GPU test suite, smoke(), the
 # headline bench, its rocprofv3 kernel summary, the two PMC passes for HBM traffic (separate runs, counters
-# only), and the chain benchmarks with their kernel summary.  Everything lands in gpurun_out/final/;
-# the summaries worth keeping are copied into profiles/ by hand afterwards.
+# only), and the chain benchmarks (cold and cache-resident inputs) with their kernel summary.  Everything lands in
+# gpurun_out/final/; `python tools/copy_profiles.py <tag>` then copies the summaries into profiles/r02_*_<tag>.*.
 set -eo pipefail
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out/final
@@ -15,10 +15,11 @@ echo "== bench"; (cd "$R" && timeout -k 10 300 python bench.py) 2>/dev/null | ta
 echo "== rocprof bench"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_bench" -- python3 "$R/bench.py" --no-cpu-baseline > "$O/prof_bench.log" 2>&1
 echo "== pmc fetch"
-timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/pmc_fetch" -- python3 "$R/bench.py" --steps 5 --warmup 2 --no-cpu-baseline > "$O/pmc_fetch.log" 2>&1
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/pmc_fetch" -- python3 "$R/bench.py" --steps 12 --warmup 6 --no-cpu-baseline > "$O/pmc_fetch.log" 2>&1
 echo "== pmc write"
-timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$O/pmc_write" -- python3 "$R/bench.py" --steps 5 --warmup 2 --no-cpu-baseline > "$O/pmc_write.log" 2>&1
-echo "== chains"; (cd "$R" && timeout -k 10 600 python tools/bench_chains.py) 2>/dev/null > "$O/chains.jsonl"; wc -l "$O/chains.jsonl"
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$O/pmc_write" -- python3 "$R/bench.py" --steps 12 --warmup 6 --no-cpu-baseline > "$O/pmc_write.log" 2>&1
+echo "== chains (cold inputs)"; (cd "$R" && timeout -k 10 600 python tools/bench_chains.py) 2>/dev/null > "$O/chains.jsonl"; wc -l "$O/chains.jsonl"
+echo "== chains (cache-resident inputs)"; (cd "$R" && timeout -k 10 600 python tools/bench_chains.py --warm --only denoise,mfcc,fastconv,pitch,mvdr) 2>/dev/null > "$O/chains_warm.jsonl"; wc -l "$O/chains_warm.jsonl"
 echo "== rocprof chains"
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_chains" -- python3 "$R/tools/bench_chains.py" --iters 8 > "$O/prof_chains.log" 2>&1
 find "$O" -name "*kernel_stats.csv" -o -name "*counter_collection.csv" | head
