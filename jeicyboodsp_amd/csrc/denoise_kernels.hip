@@ -587,6 +587,75 @@ __device__ __forceinline__ void denoise_frame_nreg(const unsigned int *raw, cons
     wave_lds_fence();
 }
 
+// The frame with every mirror pair of bins owned by one lane (frame_io.h, PairTwiddles): five items per lane, the gain
+// evaluated on the 640 bins m, m + 512 (m = lane + 64 d, d < 5) and the rest of the inverse transform's input taken
+// from the Hermitian symmetry -- which holds because the gain is real and N[1024 - k] = N[k] up to the rounding of the
+// estimate (|X[k]| and |X[1024 - k]| of a real frame, 1e-7 apart in FP32; the reference's own FFTW spectrum is
+// symmetric to 1e-16).  The reference's 1/1024 after the inverse transform (SS:248, a power of two: exact wherever it
+// is applied) is folded into the gain, so the noise values arrive pre-multiplied by it.
+#ifndef JDSP_DENOISE_PAIRS
+#define JDSP_DENOISE_PAIRS 1
+#endif
+struct NoisePairRegs { float lo[5], hi[5]; };
+template <int MODE>
+__device__ __forceinline__ void load_noise_pair_regs(NoisePairRegs &n, const float *__restrict__ row, int lane)
+{
+    // spectral subtraction: N / 1024; Wiener: N as is (its gain is a ratio)
+    const float sc = MODE == 0 ? (1.0f / 1024.0f) : 1.0f;
+#pragma unroll
+    for (int d = 0; d < 5; d++) { n.lo[d] = sc * row[lane + 64 * d]; n.hi[d] = sc * row[lane + 64 * d + 512]; }
+}
+
+// apply_gain<MODE>(x, n) / 1024 with n as load_noise_pair_regs left it
+template <int MODE>
+__device__ __forceinline__ float2 apply_gain_scaled(float2 x, float n)
+{
+    const float c = 1.0f / 1024.0f;
+    const float p = x.x * x.x + x.y * x.y;
+    if (MODE == 0) {
+        const float g = c - n * __frsqrt_rn(p);              // (|X| - N) / (1024 |X|); p == 0 gives inf / NaN, replaced below
+        const bool zero = p == 0.0f;
+        return make_float2(zero ? -n : x.x * g, zero ? 0.0f : x.y * g);
+    } else {
+        float r = (n * n) * __frcp_rn(p);                    // 0 * inf = NaN keeps the reference's 0/0
+        if (r >= 1.0f) r = 1.0f;
+        const float g = c - c * r;
+        return make_float2(x.x * g, x.y * g);
+    }
+}
+
+template <int MODE>
+__device__ __forceinline__ void denoise_frame_pairs(const unsigned int *raw, const FrameTables &t, const PairTwiddles &pw,
+                                                    float2 *lds, int lane, const NoisePairRegs &n, float2 (&y)[8])
+{
+    float2 v[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const float2 s = unpack_i16x2(raw[r]);
+        v[r] = make_float2(s.x * t.win[r].x, s.y * t.win[r].y);
+    }
+    wave_fft512<false>(v, lds, lane, t.tw);
+    float2 zr[5], ret[4];
+    wave_lds_fence();                                            // the transform's last exchange reads are done
+    pair_fetch_lds(v, lds, lane, zr);
+#pragma unroll
+    for (int d = 0; d < 5; d++) {
+        const float2 e = cadd_conj(v[d], zr[d]);
+        const float2 o = csub_conj_mj(v[d], zr[d]);
+        const float2 p = cmul(pw.w[d], o);
+        const float2 lo = apply_gain_scaled<MODE>(cadd(e, p), n.lo[d]);      // Y[m] / 1024
+        const float2 hi = apply_gain_scaled<MODE>(csub(e, p), n.hi[d]);      // Y[m + 512] / 1024
+        if (d < 4) {
+            presplit_inv_pair(lo, hi, pw.w[d], y[d], ret[d]);
+        } else {
+            y[d] = presplit_inv_reg(lo, hi, pw.w[d]);
+        }
+    }
+    pair_return_lds(ret, lds, lane, y);
+    wave_fft512<true>(y, lds, lane, t.tw);
+    wave_lds_fence();
+}
+
 #ifndef JDSP_DENOISE_MINWAVES
 #define JDSP_DENOISE_MINWAVES 3
 #endif
@@ -694,8 +763,11 @@ __global__ __launch_bounds__(64, JDSP_DENOISE_MINWAVES) void denoise_kernel(
 // 24 of work; with run = 22 it is 2,979 waves, one round, 23 frame times -- and the halo overhead falls from 1/8 to
 // 1/22.  A wave needs the next block's samples only one iteration later, so they are loaded at the top of the
 // iteration that precedes their use (4 dwords per lane) instead of all K + 2 blocks up front (40 VGPRs at K = 8).
+#ifndef JDSP_DENOISE_RESIDENT
+#define JDSP_DENOISE_RESIDENT (JDSP_DENOISE_PAIRS ? 4 : 3)      // waves per SIMD the run kernel's register budget allows
+#endif
 template <int MODE>
-__global__ __launch_bounds__(64, JDSP_DENOISE_MINWAVES) void denoise_run_kernel(
+__global__ __launch_bounds__(64, JDSP_DENOISE_RESIDENT) void denoise_run_kernel(
     const short *__restrict__ pcm, long n_blocks, long calls_before, const DenoiseState *__restrict__ st_in,
     DenoiseState *st_out, const int *__restrict__ ver_base, const unsigned long long *__restrict__ snap_mask,
     const float *__restrict__ noise_rows, const float2 *__restrict__ table, short *__restrict__ out,
@@ -710,12 +782,22 @@ __global__ __launch_bounds__(64, JDSP_DENOISE_MINWAVES) void denoise_run_kernel(
 
     FrameTables t;
     load_frame_tables(t, table, lane);
+#if JDSP_DENOISE_PAIRS
+    PairTwiddles sw;
+    load_pair_twiddles(sw, table, lane);
+    NoisePairRegs nz;
+#define JDSP_RUN_LOAD_NOISE(ROW) load_noise_pair_regs<MODE>(nz, ROW, lane)
+#define JDSP_RUN_FRAME() denoise_frame_pairs<MODE>(raw, t, sw, lds, lane, nz, y)
+#else
     SplitTwiddles sw;
     load_split_twiddles(sw, table, lane);
+    NoiseRegs nz;
+#define JDSP_RUN_LOAD_NOISE(ROW) load_noise_regs(nz, ROW, lane)
+#define JDSP_RUN_FRAME() denoise_frame_nreg<MODE>(raw, t, sw, lds, lane, nz, y)
+#endif
 
     unsigned int raw[8], nxt[4];
     float2 tail[4], y[8];
-    NoiseRegs nz;
     const float *cur_row = nullptr;
     load_block_pairs(pcm, n_blocks, st_in, j0 - 2, lane, nxt);
 #pragma unroll
@@ -734,8 +816,8 @@ __global__ __launch_bounds__(64, JDSP_DENOISE_MINWAVES) void denoise_run_kernel(
         for (int d = 0; d < 4; d++) tail[d] = make_float2(0.f, 0.f);
     } else {
         cur_row = noise_row(noise_rows, ver_base, snap_mask, j0 - 1, sh);
-        load_noise_regs(nz, cur_row, lane);
-        denoise_frame_nreg<MODE>(raw, t, sw, lds, lane, nz, y);   // halo frame
+        JDSP_RUN_LOAD_NOISE(cur_row);
+        JDSP_RUN_FRAME();                                          // halo frame
 #pragma unroll
         for (int d = 0; d < 4; d++) tail[d] = y[d + 4];
     }
@@ -752,9 +834,9 @@ __global__ __launch_bounds__(64, JDSP_DENOISE_MINWAVES) void denoise_run_kernel(
             const float *row = noise_row(noise_rows, ver_base, snap_mask, j, sh);
             if (row != cur_row) {                                // wave-uniform: a new estimate was latched
                 cur_row = row;
-                load_noise_regs(nz, row, lane);
+                JDSP_RUN_LOAD_NOISE(row);
             }
-            denoise_frame_nreg<MODE>(raw, t, sw, lds, lane, nz, y);
+            JDSP_RUN_FRAME();
         }
         float2 o[4];
 #pragma unroll
@@ -781,6 +863,9 @@ __global__ __launch_bounds__(64, JDSP_DENOISE_MINWAVES) void denoise_run_kernel(
         }
     }
 }
+
+#undef JDSP_RUN_LOAD_NOISE
+#undef JDSP_RUN_FRAME
 
 // ---------------------------------------------------------------------------------------
 // Multi-GPU sharding of the noise estimate.  Rank r owns blocks [b0, b1) of the
@@ -1001,9 +1086,9 @@ int launch_denoise(hipStream_t s, int mode, int k_opt, int n_cu, const short *pc
         sh.emit_to = n_blocks;
     }
     if (k_opt == 0) {
-        // one round of resident waves: 3 per SIMD (JDSP_DENOISE_MINWAVES), 4 SIMDs per CU; never fewer than 4 blocks
+        // one round of resident waves: JDSP_DENOISE_RESIDENT per SIMD, 4 SIMDs per CU; never fewer than 4 blocks
         // per wave (a quarter of halo overhead at most)
-        const long slots = (long)(n_cu > 0 ? n_cu : 256) * 4 * JDSP_DENOISE_MINWAVES;
+        const long slots = (long)(n_cu > 0 ? n_cu : 256) * 4 * JDSP_DENOISE_RESIDENT;
         long waves = (n_blocks + 3) / 4;
         if (waves > slots) waves = slots;
         long run = (n_blocks + waves - 1) / waves;

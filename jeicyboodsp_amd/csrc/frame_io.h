@@ -141,6 +141,60 @@ __device__ __forceinline__ float2 presplit_inv_reg(float2 ylo, float2 yhi, float
     return cadd_pj(s, r);
 }
 
+// ---- the split steps with every mirror pair owned by ONE lane ------------------------------------------------------
+// split_fwd_reg hands each lane X[m] and X[m + 512] for its eight m = l + 64 d: all 1024 bins of the frame, i.e. every
+// pair {X[k], X[1024 - k]} twice over (a real frame's spectrum is Hermitian), and a per-bin stage that keeps the spectrum
+// Hermitian (a real gain that is the same for k and 1024 - k) pays for sixteen bins per lane where eight are distinct.
+// Here lane l works on m = l + 64 d for d = 0..4 only -- the bins m and m + 512 of 320 values of m -- and gets the rest
+// of the inverse transform's input from the symmetry: with s = Y[m] + Y[m+512], r = (Y[m] - Y[m+512]) conj(W^m),
+//     Z'[m] = s + j r  (presplit_inv_reg)     and     Z'[512 - m] = conj(s - j r),
+// the second going to whoever holds bin 512 - m (lane 64 - l, register 7 - d; lane 0: its own register 8 - d).  Lane l
+// keeps Z'[l + 64 d] for d <= 4 and receives registers 5..7; the pairs of d = 3, 4 overlap (m = 192 + l and 256 + (64 - l)
+// are mirrors) so that every lane runs the same five items and no lane needs a special case.  Five split / per-bin /
+// pre-split items per lane instead of eight, ten per-bin evaluations instead of sixteen, ten noise values and five
+// twiddles in registers instead of sixteen and eight; the LDS moves the same nine + eight vectors as mirror_fetch_lds.
+struct PairTwiddles { float2 w[5]; };
+
+__device__ __forceinline__ void load_pair_twiddles(PairTwiddles &t, const float2 *__restrict__ table, int lane)
+{
+#pragma unroll
+    for (int d = 0; d < 5; d++) t.w[d] = table[kStftSplit + lane + 64 * d];
+}
+
+// zr[d] = Zh[512 - (lane + 64 d)], d = 0..4: registers 3..7 of the other lanes (and slot 512 = Zh[0]).  `img` must not
+// be in use (fence before this if the transform's last exchange may still be reading it).
+__device__ __forceinline__ void pair_fetch_lds(const float2 (&v)[8], float2 *img, int lane, float2 (&zr)[5])
+{
+#pragma unroll
+    for (int d = 3; d < 8; d++) img[lane + 64 * d] = v[d];
+    if (lane == 0) img[512] = v[0];
+    wave_lds_fence();
+#pragma unroll
+    for (int d = 0; d < 5; d++) zr[d] = img[512 - lane - 64 * d];
+    wave_lds_fence();
+}
+
+// One item: from Y[m], Y[m + 512] the two inverse-transform inputs Z'[m] and Z'[512 - m]
+__device__ __forceinline__ void presplit_inv_pair(float2 ylo, float2 yhi, float2 w, float2 &zk, float2 &zmirror)
+{
+    const float2 s = cadd(ylo, yhi);
+    const float2 r = cmul_conj(csub(ylo, yhi), w);
+    zk = cadd_pj(s, r);
+    zmirror = cconj_sub_j(s, r);
+}
+
+// y[0..4] hold Z'[lane + 64 d]; ret[d] = Z'[512 - lane - 64 d] for d = 0..3 go to their owners, and y[5..7] come back.
+// (Slots 257..319 and 512 receive values nobody reads.)
+__device__ __forceinline__ void pair_return_lds(const float2 (&ret)[4], float2 *img, int lane, float2 (&y)[8])
+{
+#pragma unroll
+    for (int d = 0; d < 4; d++) img[512 - lane - 64 * d] = ret[d];
+    wave_lds_fence();
+#pragma unroll
+    for (int d = 5; d < 8; d++) y[d] = img[lane + 64 * d];
+    wave_lds_fence();
+}
+
 struct FrameTables {
     WaveTwiddles tw;
     float2 win[8];     // per lane: window pair of samples (2 lane + 128 r, +1), halved

@@ -48,6 +48,7 @@ JDSP_PK_ADD(cadd_mj, "op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]")         // a -
 JDSP_PK_ADD(cadd_pj, "op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]")         // a + j b = (a.x - b.y, a.y + b.x)
 JDSP_PK_ADD(cadd_conj, "neg_hi:[0,1]")                                    // a + conj(b)
 JDSP_PK_ADD(csub_conj_mj, "op_sel:[1,1] op_sel_hi:[0,0] neg_hi:[1,0]")    // -j (a - conj(b)) = (a.y + b.y, b.x - a.x)
+JDSP_PK_ADD(cconj_sub_j, "op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[1,0]")     // conj(a - j b) = (a.x + b.y, b.x - a.y)
 #undef JDSP_PK_ADD
 
 // d = c + s * a  /  c - s * a  with a real scale s held in both halves of `s2`, and the same with a
