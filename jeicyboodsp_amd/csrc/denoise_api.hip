@@ -5,7 +5,8 @@ using jdsp::fail;
 
 static void free_workspace(jdsp_denoise *h)
 {
-    void *p[] = {h->flags, h->ev_n, h->ver_base, h->snap_mask, h->events, h->dbg_energy, h->dbg_zcr, h->mag, h->rows};
+    void *p[] = {h->flags, h->ev_n, h->ver_base, h->snap_mask, h->events, h->dbg_energy, h->dbg_zcr, h->mag, h->rows,
+                 h->acc.lat_alpha, h->acc.lat_chunk, h->acc.chunk_alpha, h->acc.chunk_beta, h->acc.a_start};
     for (void *q : p)
         if (q) (void)hipFree(q);
     h->flags = nullptr;
@@ -14,6 +15,9 @@ static void free_workspace(jdsp_denoise *h)
     h->dbg_energy = nullptr;
     h->dbg_zcr = nullptr;
     h->mag = h->rows = nullptr;
+    h->acc.lat_alpha = h->acc.chunk_alpha = h->acc.chunk_beta = h->acc.a_start = nullptr;
+    h->acc.lat_chunk = nullptr;
+    h->cap_rows = 0;
     h->cap_blocks = 0;
     h->cap_mag = 0;
 }
@@ -135,7 +139,7 @@ static int reserve2(jdsp_denoise *h, long max_blocks, long mag_blocks);
 int jdsp_denoise_reserve(jdsp_denoise *h, long max_blocks)
 {
     if (!h || max_blocks < 0) return JDSP_EINVAL;
-    return reserve2(h, max_blocks, max_blocks);
+    return reserve2(h, max_blocks, 0);
 }
 
 // max_blocks: blocks the run-length plan covers; mag_blocks: blocks whose magnitudes this GPU may hold
@@ -156,16 +160,24 @@ static int reserve2(jdsp_denoise *h, long max_blocks, long mag_blocks)
     if (e == hipSuccess) e = hipMalloc((void **)&h->events, n * sizeof(int));
     if (e == hipSuccess) e = hipMalloc((void **)&h->dbg_energy, n * sizeof(long long));
     if (e == hipSuccess) e = hipMalloc((void **)&h->dbg_zcr, n * sizeof(int));
-    // worst case: every block feeds the noise average; an estimate can latch at most every 10th block
-    const size_t nm = (size_t)(mag_blocks > 0 ? mag_blocks : 1);
-    if (e == hipSuccess) e = hipMalloc((void **)&h->mag, nm * 1024 * sizeof(float));
-    if (e == hipSuccess) e = hipMalloc((void **)&h->rows, (nm / 10 + 2) * 1024 * sizeof(float));
+    // worst case: every block feeds the noise average; an estimate can latch at most every 10th block.  Magnitude rows
+    // are kept by sharded runs only (the one-GPU path folds them into per-chunk maps in registers, noise_accum_kernel).
+    if (e == hipSuccess && mag_blocks > 0) e = hipMalloc((void **)&h->mag, (size_t)mag_blocks * 1024 * sizeof(float));
+    const size_t n_rows = (n > (size_t)mag_blocks ? n : (size_t)mag_blocks) / 10 + 2;
+    if (e == hipSuccess) e = hipMalloc((void **)&h->rows, n_rows * 1024 * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void **)&h->acc.lat_alpha, n_rows * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void **)&h->acc.lat_chunk, n_rows * sizeof(int));
+    const size_t n_chunks = n < (size_t)jdsp::kNoiseChunks ? (n > 0 ? n : 1) : (size_t)jdsp::kNoiseChunks;   // launch_noise_estimate's grid
+    if (e == hipSuccess) e = hipMalloc((void **)&h->acc.chunk_alpha, n_chunks * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void **)&h->acc.chunk_beta, n_chunks * 1024 * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void **)&h->acc.a_start, n_chunks * 1024 * sizeof(float));
     if (e != hipSuccess) {
         free_workspace(h);
         return fail(ctx, e == hipErrorOutOfMemory ? JDSP_ENOMEM : JDSP_EHIP, "jdsp_denoise_reserve", e);
     }
     h->cap_blocks = max_blocks;
     h->cap_mag = mag_blocks;
+    h->cap_rows = (long)n_rows;
     return JDSP_OK;
 }
 
@@ -193,7 +205,7 @@ int jdsp_denoise_process_dev(jdsp_denoise *h, const int16_t *pcm_dev, long n_blo
             jdsp::launch_denoise_plan(s, h->flags, n_blocks, st_in, st_out, h->ver_base, h->snap_mask, h->events, h->ev_n,
                                       h->plan) ||
             jdsp::launch_noise_estimate512(s, pcm_dev, n_blocks, st_in, st_out, h->events, h->ev_n, h->plan,
-                                           ctx->stft1024_table, h->win512h, h->mag, h->rows) ||
+                                           h->ver_base, h->snap_mask, ctx->stft1024_table, h->win512h, h->acc, h->rows) ||
             jdsp::launch_denoise512(s, h->mode, pcm_dev, n_blocks, h->calls, st_in, st_out, h->ver_base, h->snap_mask,
                                     h->rows, ctx->stft1024_table, h->win512h, out_dev, precast_dev))
             return fail(ctx, JDSP_EHIP, "denoise512 launch", hipGetLastError());
@@ -207,7 +219,7 @@ int jdsp_denoise_process_dev(jdsp_denoise *h, const int16_t *pcm_dev, long n_blo
         jdsp::launch_denoise_plan(s, h->flags, n_blocks, st_in, st_out, h->ver_base, h->snap_mask, h->events, h->ev_n,
                                   h->plan) ||
         jdsp::launch_noise_estimate(s, pcm_dev, n_blocks, st_in, st_out, h->events, h->ev_n, h->plan,
-                                    ctx->stft1024_table, h->mag, h->rows) ||
+                                    h->ver_base, h->snap_mask, ctx->stft1024_table, h->acc, h->rows) ||
         jdsp::launch_denoise(s, h->mode, h->opt_k, ctx->n_cu, pcm_dev, n_blocks, h->calls, st_in, st_out, h->ver_base,
                              h->snap_mask, h->rows, ctx->stft1024_table, out_dev, precast_dev))
         return fail(ctx, JDSP_EHIP, "denoise launch", hipGetLastError());

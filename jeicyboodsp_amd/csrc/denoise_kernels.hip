@@ -367,62 +367,133 @@ __device__ __forceinline__ void mag_store_j(const float2 *lds, int lane, const f
         make_float2(sqrtf(hi0.x * hi0.x + hi0.y * hi0.y), sqrtf(hi1.x * hi1.x + hi1.y * hi1.y));
 }
 
-__global__ __launch_bounds__(64) void noise_mag_kernel(const short *__restrict__ pcm, long n_blocks,
-                                                       const DenoiseState *__restrict__ st_in,
-                                                       const int *__restrict__ events,
-                                                       const DenoisePlan *__restrict__ plan,
-                                                       const float2 *__restrict__ table, float *__restrict__ mag)
+// ---------------------------------------------------------------------------------------
+// A12 (SS:165-193), the noise average: at every EstimateNoiseSpectrum event  A += |X|;  from run length 3 on  A /= 2;  at
+// run length 10 the average is latched as the estimate.  Over the events of a call that is a chain of affine maps
+// A <- h (A + |X|), h in {1, 1/2}: sequential by definition, and speech is 40-60 % pauses -- a 65,536-block call can hold
+// tens of thousands of events.  (Walked one event after the other, one thread per bin, that chain took 0.26 us per event:
+// 8.9 ms per 65,536 blocks of a stream that is half pauses, against 0.1 ms for everything else;
+// tools/denoise_events_probe.py.)  So the chain is cut into chunks:
+//   noise_accum_kernel    one wave per chunk of C consecutive events (C = 1 up to kNoiseChunks events, else
+//                         ceil(events / grid)): transforms each event's frame, keeps the chunk's map
+//                         A -> alpha A + beta[bin] in registers (alpha a power of two), and writes it once; at a latch it
+//                         writes the map so far into the latched row.  No magnitude ever goes to memory.
+//   noise_combine_kernel  16 bins per workgroup, 64 groups of chunks per bin: composes each group's maps, walks the 64
+//                         group maps from the carried-in average, expands to the average entering every chunk, and
+//                         completes the latched rows:  row = alpha_so_far * A_entering_chunk + beta_so_far.
+// Multiplying by a power of two commutes with rounding, so with one event per chunk and one chunk per group -- up to 64
+// events per call, e.g. any per-block or small-batch streaming use -- the result is bit-identical to the sequential
+// walk; beyond that the additions associate differently (1e-7 relative, the same size as FP32 against the reference's FP64).
+struct ChunkGeom { int per_chunk, n_chunks; };
+__device__ __forceinline__ ChunkGeom chunk_geom(int n_events, int grid)
 {
-    __shared__ __attribute__((aligned(16))) float2 lds[kWaveLdsComplex];
-    __shared__ __attribute__((aligned(16))) unsigned int stage[256];
-    const int lane = threadIdx.x;
-    const int n_events = plan->n_events;
-    if ((int)blockIdx.x >= n_events) return;
-    FrameTables t;
-    load_frame_tables(t, table, lane);
-    for (int e = blockIdx.x; e < n_events; e += gridDim.x) {
-        const long j = events[e];
-        const u32x4 h0 = load_block(pcm, n_blocks, st_in, j - 1, lane);   // rgssKeepBuffer (SS:165-170)
-        const u32x4 h1 = load_block(pcm, n_blocks, st_in, j, lane);
-        unsigned int raw[8];
-        relayout_half(stage, lane, h0, raw);
-        relayout_half(stage, lane, h1, raw + 4);
-        forward_to_lds(raw, t, lds, lane);
-        float *dst = mag + (size_t)e * 1024;
-        mag_store_j<0>(lds, lane, t.wsp, dst);
-        mag_store_j<1>(lds, lane, t.wsp, dst);
-        mag_store_j<2>(lds, lane, t.wsp, dst);
-        mag_store_j<3>(lds, lane, t.wsp, dst);
-        wave_lds_fence();
-    }
+    ChunkGeom g;
+    g.per_chunk = n_events > grid ? (n_events + grid - 1) / grid : 1;
+    g.n_chunks = (n_events + g.per_chunk - 1) / g.per_chunk;
+    return g;
 }
 
-// A12, second half: rgsdAveragedNS += |X|; from run length 3 on, /= 2 (SS:182-187); at run
-// length 10 the average is latched (SS:189-193).  noise_rows[0] is the estimate carried in.
-__global__ __launch_bounds__(256) void noise_scan_kernel(const float *__restrict__ mag,
-                                                         const int *__restrict__ ev_n,
+__global__ __launch_bounds__(64) void noise_accum_kernel(const short *__restrict__ pcm, long n_blocks,
+                                                         const DenoiseState *__restrict__ st_in,
+                                                         const int *__restrict__ events, const int *__restrict__ ev_n,
                                                          const DenoisePlan *__restrict__ plan,
-                                                         const DenoiseState *__restrict__ st_in, DenoiseState *st_out,
-                                                         float *__restrict__ noise_rows)
+                                                         const int *__restrict__ ver_base,
+                                                         const unsigned long long *__restrict__ snap_mask,
+                                                         const float2 *__restrict__ table, NoiseAccum acc,
+                                                         float *__restrict__ noise_rows, int latch_run)
 {
-    const int bin = blockIdx.x * blockDim.x + threadIdx.x;      // 0..1023
-    float avg = st_in->avg[bin];
-    float cur = st_in->noise[bin];
-    noise_rows[bin] = cur;
+    __shared__ __attribute__((aligned(16))) float2 lds[kWaveLdsComplex];
+    const int lane = threadIdx.x;
     const int n_events = plan->n_events;
-    int row = 0;
-    for (int e = 0; e < n_events; e++) {
+    const ChunkGeom cg = chunk_geom(n_events, (int)gridDim.x);
+    const int chunk = blockIdx.x;
+    if (chunk >= cg.n_chunks) return;
+    const int e0 = chunk * cg.per_chunk;
+    const int e1 = e0 + cg.per_chunk < n_events ? e0 + cg.per_chunk : n_events;
+    FrameTables t;
+    load_frame_tables(t, table, lane);
+    SplitTwiddles sw;
+    load_split_twiddles(sw, table, lane);
+    float blo[8], bhi[8], alpha = 1.0f;                          // beta[lane + 64 d], beta[lane + 64 d + 512]
+#pragma unroll
+    for (int d = 0; d < 8; d++) blo[d] = bhi[d] = 0.0f;
+    for (int e = e0; e < e1; e++) {
+        const long j = events[e];
         const int n = ev_n[e];
-        avg += mag[(size_t)e * 1024 + bin];
-        if (n >= 3) avg *= 0.5f;
-        if (n == 10) {
-            row++;
-            cur = avg;
-            noise_rows[(size_t)row * 1024 + bin] = cur;
+        unsigned int prev[4], cur[4];
+        load_block_pairs(pcm, n_blocks, st_in, j - 1, lane, prev);   // rgssKeepBuffer (SS:165-170)
+        load_block_pairs(pcm, n_blocks, st_in, j, lane, cur);
+        float2 v[8], zr[8], lo[8], hi[8];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const float2 s0 = unpack_i16x2(prev[r]), s1 = unpack_i16x2(cur[r]);
+            v[r] = make_float2(s0.x * t.win[r].x, s0.y * t.win[r].y);
+            v[r + 4] = make_float2(s1.x * t.win[r + 4].x, s1.y * t.win[r + 4].y);
+        }
+        wave_fft512<false>(v, lds, lane, t.tw);
+        wave_lds_fence();
+        mirror_fetch_lds(v, lds, lane, zr);
+        split_fwd_reg(v, zr, sw, lo, hi);
+        const float h = n >= 3 ? 0.5f : 1.0f;                    // SS:182-187
+#pragma unroll
+        for (int d = 0; d < 8; d++) {
+            blo[d] = (blo[d] + sqrtf(lo[d].x * lo[d].x + lo[d].y * lo[d].y)) * h;
+            bhi[d] = (bhi[d] + sqrtf(hi[d].x * hi[d].x + hi[d].y * hi[d].y)) * h;
+        }
+        alpha *= h;
+        if (n == latch_run) {                                    // SS:189-193
+            const int row = version_of(ver_base, snap_mask, j);
+            float *dst = noise_rows + (size_t)row * 1024 + lane;
+#pragma unroll
+            for (int d = 0; d < 8; d++) { dst[64 * d] = blo[d]; dst[64 * d + 512] = bhi[d]; }
+            if (lane == 0) { acc.lat_alpha[row] = alpha; acc.lat_chunk[row] = chunk; }
         }
     }
-    st_out->avg[bin] = avg;
-    st_out->noise[bin] = cur;
+    float *dst = acc.chunk_beta + (size_t)chunk * 1024 + lane;
+#pragma unroll
+    for (int d = 0; d < 8; d++) { dst[64 * d] = blo[d]; dst[64 * d + 512] = bhi[d]; }
+    if (lane == 0) acc.chunk_alpha[chunk] = alpha;
+}
+
+// grid: n_bins / 16 workgroups of 1024 threads = 16 bins x 64 chunk groups; accum_grid = noise_accum's grid size
+__global__ __launch_bounds__(1024) void noise_combine_kernel(const DenoisePlan *__restrict__ plan,
+                                                             const DenoiseState *__restrict__ st_in, DenoiseState *st_out,
+                                                             NoiseAccum acc, float *__restrict__ noise_rows, int accum_grid)
+{
+    __shared__ float ga[64][16], gb[64][16];
+    const int bl = threadIdx.x & 15, g = threadIdx.x >> 4;
+    const int bin = blockIdx.x * 16 + bl;
+    const int n_snap = plan->n_snap;
+    const ChunkGeom cg = chunk_geom(plan->n_events, accum_grid);
+    const int per_group = (cg.n_chunks + 63) >> 6;
+    const int c0 = g * per_group < cg.n_chunks ? g * per_group : cg.n_chunks;
+    const int c1 = c0 + per_group < cg.n_chunks ? c0 + per_group : cg.n_chunks;
+    {
+        float a = 1.0f, b = 0.0f;                                 // this group's chunks composed
+        for (int c = c0; c < c1; c++) {
+            const float ac = acc.chunk_alpha[c];
+            b = ac * b + acc.chunk_beta[(size_t)c * 1024 + bin];
+            a *= ac;
+        }
+        ga[g][bl] = a;
+        gb[g][bl] = b;
+    }
+    __syncthreads();
+    float A = st_in->avg[bin];
+    for (int q = 0; q < g; q++) A = ga[q][bl] * A + gb[q][bl];   // the average entering this group
+    for (int c = c0; c < c1; c++) {
+        acc.a_start[(size_t)c * 1024 + bin] = A;
+        A = acc.chunk_alpha[c] * A + acc.chunk_beta[(size_t)c * 1024 + bin];
+    }
+    if (g == 63) st_out->avg[bin] = A;                           // groups past the last chunk are identities
+    if (g == 0) noise_rows[bin] = st_in->noise[bin];             // row 0: the estimate carried in
+    __syncthreads();                                             // a_start is read back by other threads of this workgroup
+    for (int r = 1 + g; r <= n_snap; r += 64) {
+        float *row = noise_rows + (size_t)r * 1024 + bin;
+        *row = acc.lat_alpha[r] * acc.a_start[(size_t)acc.lat_chunk[r] * 1024 + bin] + *row;
+    }
+    __syncthreads();
+    if (g == 0) st_out->noise[bin] = n_snap > 0 ? noise_rows[(size_t)n_snap * 1024 + bin] : st_in->noise[bin];
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1050,14 +1121,14 @@ int launch_run_plan(hipStream_t s, const unsigned char *flags, long n_blocks, co
 
 int launch_noise_estimate(hipStream_t s, const short *pcm, long n_blocks, const DenoiseState *st_in,
                           DenoiseState *st_out, const int *events, const int *ev_n, const DenoisePlan *plan,
-                          const float2 *table, float *mag, float *noise_rows)
+                          const int *ver_base, const unsigned long long *snap_mask, const float2 *table,
+                          const NoiseAccum &acc, float *noise_rows)
 {
-    if (n_blocks > 0) {
-        const long grid = n_blocks < 4096 ? n_blocks : 4096;       // waves stride over the event list
-        hipLaunchKernelGGL(noise_mag_kernel, dim3((unsigned)grid), dim3(64), 0, s, pcm, n_blocks, st_in, events, plan,
-                           table, mag);
-    }
-    hipLaunchKernelGGL(noise_scan_kernel, dim3(4), dim3(256), 0, s, mag, ev_n, plan, st_in, st_out, noise_rows);
+    const int grid = n_blocks < kNoiseChunks ? (int)(n_blocks > 0 ? n_blocks : 1) : kNoiseChunks;
+    if (n_blocks > 0)
+        hipLaunchKernelGGL(noise_accum_kernel, dim3((unsigned)grid), dim3(64), 0, s, pcm, n_blocks, st_in, events, ev_n, plan,
+                           ver_base, snap_mask, table, acc, noise_rows, 10);
+    hipLaunchKernelGGL(noise_combine_kernel, dim3(1024 / 16), dim3(1024), 0, s, plan, st_in, st_out, acc, noise_rows, grid);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
@@ -1164,27 +1235,58 @@ __device__ __forceinline__ void dn512_forward(const float (&xa)[8], const float 
     wave_lds_fence();
 }
 
-// |A[k]|, |B[k]| of the frame pair for every bin (A12 on 512-point frames): events e and e+1 share a transform
-__global__ __launch_bounds__(64) void noise_mag512_kernel(const short *__restrict__ pcm, long n_blocks,
-                                                          const DenoiseState *__restrict__ st_in,
-                                                          const int *__restrict__ events,
-                                                          const DenoisePlan *__restrict__ plan,
-                                                          const float2 *__restrict__ table,
-                                                          const float *__restrict__ win512, float *__restrict__ mag)
+// A12 on 512-point frames, chunked like noise_accum_kernel; events e and e + 1 of a chunk share a transform (frame pair
+// a + j b).  |X[512 - k]| = |X[k]| of a real frame: lane l keeps the maps of bins l + 64 q (q < 4) and writes each to its
+// mirror bin as well (the carried-in average is symmetric for the same reason); bin 256 is lane 0's.
+__global__ __launch_bounds__(64) void noise_accum512_kernel(const short *__restrict__ pcm, long n_blocks,
+                                                            const DenoiseState *__restrict__ st_in,
+                                                            const int *__restrict__ events, const int *__restrict__ ev_n,
+                                                            const DenoisePlan *__restrict__ plan,
+                                                            const int *__restrict__ ver_base,
+                                                            const unsigned long long *__restrict__ snap_mask,
+                                                            const float2 *__restrict__ table,
+                                                            const float *__restrict__ win512, NoiseAccum acc,
+                                                            float *__restrict__ noise_rows, int latch_run)
 {
     __shared__ __attribute__((aligned(16))) float2 lds[kWaveLdsComplex];
     const int lane = threadIdx.x;
     const int n_events = plan->n_events;
-    const int n_pairs = (n_events + 1) >> 1;
-    if ((int)blockIdx.x >= n_pairs) return;
+    const ChunkGeom cg = chunk_geom(n_events, (int)gridDim.x);
+    const int chunk = blockIdx.x;
+    if (chunk >= cg.n_chunks) return;
+    const int e0 = chunk * cg.per_chunk;
+    const int e1 = e0 + cg.per_chunk < n_events ? e0 + cg.per_chunk : n_events;
     WaveTwiddles tw;
     load_wave_twiddles(tw, table, lane);
     float win[8];
 #pragma unroll
     for (int r = 0; r < 8; r++) win[r] = win512[lane + 64 * r];
     const long n_samples = n_blocks * 256;
-    for (int p = blockIdx.x; p < n_pairs; p += gridDim.x) {
-        const int ea = 2 * p, eb = 2 * p + 1 < n_events ? 2 * p + 1 : 2 * p;
+    float b[4] = {0.f, 0.f, 0.f, 0.f}, b256 = 0.f, alpha = 1.0f;
+    auto put = [&](float *row) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int k = lane + 64 * q;
+            row[k] = b[q];
+            row[(512 - k) & 511] = b[q];
+        }
+        if (lane == 0) row[256] = b256;
+    };
+    auto step = [&](const float (&m)[4], float m256, int e) {
+        const int n = ev_n[e];
+        const float h = n >= 3 ? 0.5f : 1.0f;                    // SS:182-187
+#pragma unroll
+        for (int q = 0; q < 4; q++) b[q] = (b[q] + m[q]) * h;
+        b256 = (b256 + m256) * h;
+        alpha *= h;
+        if (n == latch_run) {                                    // SS:189-193
+            const int row = version_of(ver_base, snap_mask, events[e]);
+            put(noise_rows + (size_t)row * 1024);
+            if (lane == 0) { acc.lat_alpha[row] = alpha; acc.lat_chunk[row] = chunk; }
+        }
+    };
+    for (int e = e0; e < e1; e += 2) {
+        const int ea = e, eb = e + 1 < e1 ? e + 1 : e;
         const long sa = ((long)events[ea] - 1) * 256, sb = ((long)events[eb] - 1) * 256;   // [previous block, block] (SS:165-170)
         float xa[8], xb[8];
 #pragma unroll
@@ -1193,23 +1295,22 @@ __global__ __launch_bounds__(64) void noise_mag512_kernel(const short *__restric
             xb[r] = dn512_sample(pcm, n_samples, st_in, sb + lane + 64 * r);
         }
         dn512_forward(xa, xb, win, tw, lds, lane);
-        float *da = mag + (size_t)ea * 1024, *db = mag + (size_t)eb * 1024;
+        float ma[4], mb[4];
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const int k = lane + 64 * q;
             const float2 zk = lds[k], zm = lds[512 - k];
             const float2 A = cadd_conj(zk, zm), B = csub_conj_mj(zk, zm);
-            const float ma = sqrtf(A.x * A.x + A.y * A.y), mb = sqrtf(B.x * B.x + B.y * B.y);
-            da[k] = ma; da[(512 - k) & 511] = ma;                 // |X[512-k]| = |conj X[k]|
-            if (eb != ea) { db[k] = mb; db[(512 - k) & 511] = mb; }
+            ma[q] = sqrtf(A.x * A.x + A.y * A.y);
+            mb[q] = sqrtf(B.x * B.x + B.y * B.y);
         }
-        if (lane == 0) {
-            const float2 z = lds[256];
-            da[256] = fabsf(2.f * z.x);
-            if (eb != ea) db[256] = fabsf(2.f * z.y);
-        }
+        const float2 z = lds[256];
         wave_lds_fence();
+        step(ma, fabsf(2.f * z.x), ea);
+        if (eb != ea) step(mb, fabsf(2.f * z.y), eb);
     }
+    put(acc.chunk_beta + (size_t)chunk * 1024);
+    if (lane == 0) acc.chunk_alpha[chunk] = alpha;
 }
 
 template <int MODE>
@@ -1369,16 +1470,15 @@ __global__ __launch_bounds__(64, 3) void denoise512_kernel(
 
 int launch_noise_estimate512(hipStream_t s, const short *pcm, long n_blocks, const DenoiseState *st_in,
                              DenoiseState *st_out, const int *events, const int *ev_n, const DenoisePlan *plan,
-                             const float2 *table, const float *win512, float *mag, float *noise_rows)
+                             const int *ver_base, const unsigned long long *snap_mask, const float2 *table,
+                             const float *win512, const NoiseAccum &acc, float *noise_rows)
 {
-    if (n_blocks > 0) {
-        const long pairs = (n_blocks + 1) / 2;
-        const long grid = pairs < 4096 ? pairs : 4096;
-        hipLaunchKernelGGL(noise_mag512_kernel, dim3((unsigned)grid), dim3(64), 0, s, pcm, n_blocks, st_in, events, plan,
-                           table, win512, mag);
-    }
+    const int grid = n_blocks < kNoiseChunks ? (int)(n_blocks > 0 ? n_blocks : 1) : kNoiseChunks;
+    if (n_blocks > 0)
+        hipLaunchKernelGGL(noise_accum512_kernel, dim3((unsigned)grid), dim3(64), 0, s, pcm, n_blocks, st_in, events, ev_n,
+                           plan, ver_base, snap_mask, table, win512, acc, noise_rows, 10);
     // bins 0..511 only (rows keep the 1024-float pitch of the 1024-point path)
-    hipLaunchKernelGGL(noise_scan_kernel, dim3(2), dim3(256), 0, s, mag, ev_n, plan, st_in, st_out, noise_rows);
+    hipLaunchKernelGGL(noise_combine_kernel, dim3(512 / 16), dim3(1024), 0, s, plan, st_in, st_out, acc, noise_rows, grid);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

@@ -54,6 +54,16 @@ struct DenoiseState {
 };
 struct DenoisePlan { int n_events, n_snap, pad0, pad1; };
 
+// Workspace of the chunked noise average (denoise_kernels.hip, noise_accum_kernel): one affine map per chunk of events
+constexpr int kNoiseChunks = 4096;         // most chunks a call is cut into = noise_accum's largest grid (4 waves per SIMD)
+struct NoiseAccum {
+    float *chunk_alpha;    // [kNoiseChunks]
+    float *chunk_beta;     // [kNoiseChunks][1024]
+    float *a_start;        // [kNoiseChunks][1024]   the average entering each chunk
+    float *lat_alpha;      // [rows]                 per latched row: the chunk's alpha up to and including the latch
+    int *lat_chunk;        // [rows]                 ... and its chunk
+};
+
 // How denoise_kernel maps local block indices onto the (possibly global) plan and what it emits.
 struct DenoiseShard {
     long ver_block_off;        // global index of local block 0 (0 when not sharded)
@@ -124,7 +134,8 @@ int launch_vad256(hipStream_t s, const short *pcm, long n_blocks, const double *
                   long long *dbg_energy, int *dbg_zcr, int use_zcr = 1);
 int launch_noise_estimate512(hipStream_t s, const short *pcm, long n_blocks, const DenoiseState *st_in,
                              DenoiseState *st_out, const int *events, const int *ev_n, const DenoisePlan *plan,
-                             const float2 *table, const float *win512, float *mag, float *noise_rows);
+                             const int *ver_base, const unsigned long long *snap_mask, const float2 *table,
+                             const float *win512, const NoiseAccum &acc, float *noise_rows);
 int launch_denoise512(hipStream_t s, int mode, const short *pcm, long n_blocks, long calls_before,
                       const DenoiseState *st_in, DenoiseState *st_out, const int *ver_base,
                       const unsigned long long *snap_mask, const float *noise_rows, const float2 *table,
@@ -137,7 +148,8 @@ int launch_denoise_plan(hipStream_t s, const unsigned char *flags, long n_blocks
                         DenoisePlan *plan);
 int launch_noise_estimate(hipStream_t s, const short *pcm, long n_blocks, const DenoiseState *st_in,
                           DenoiseState *st_out, const int *events, const int *ev_n, const DenoisePlan *plan,
-                          const float2 *table, float *mag, float *noise_rows);
+                          const int *ver_base, const unsigned long long *snap_mask, const float2 *table,
+                          const NoiseAccum &acc, float *noise_rows);
 int launch_denoise(hipStream_t s, int mode, int k_opt, int n_cu, const short *pcm, long n_blocks, long calls_before,
                    const DenoiseState *st_in, DenoiseState *st_out, const int *ver_base,
                    const unsigned long long *snap_mask, const float *noise_rows, const float2 *table, short *out,
@@ -238,7 +250,9 @@ struct jdsp_denoise {
     long long *dbg_energy = nullptr;
     int *dbg_zcr = nullptr;
     jdsp::DenoisePlan *plan = nullptr;
-    float *mag = nullptr, *rows = nullptr;
+    float *mag = nullptr, *rows = nullptr;   // mag: sharded runs only (magnitude rows of this GPU's events)
+    long cap_rows = 0;                    // rows of `rows` / entries of acc.lat_*
+    jdsp::NoiseAccum acc = {nullptr, nullptr, nullptr, nullptr, nullptr};
     long last_blocks = 0;
     int opt_k = 0;
     int opt_vad_trace = 0;                // 1: keep every block's energy sum and ZCR for jdsp_denoise_vad_trace (slower VAD kernel)

@@ -321,3 +321,50 @@ def test_flags_only_vad_equals_the_oracle_at_the_thresholds(eng, oracle, n_fft, 
     with pytest.raises(jeicyboodsp_amd.JdspError):
         d.vad_trace(n_blocks)                           # energies / ZCR were not kept
     d.close()
+
+
+# ---- pause-heavy streams: thousands of EstimateNoiseSpectrum events per call (noise_accum / noise_combine kernels) ----
+@pytest.mark.parametrize("n_fft,block", [(1024, 512), (512, 256)])
+def test_pause_heavy_stream_matches_oracle(eng, oracle, n_fft, block):
+    """More events than noise_accum_kernel has chunks (4,096): several events per chunk, 64 groups of chunks, latches
+    in the middle of chunks.  Speech is 40-60 % pauses; here nine blocks in ten are."""
+    n_blocks = 9500
+    gen = speechlike if block == 512 else speechlike256
+    pcm = gen(77, n_blocks, pattern=[40, 3, 25, 1, 90, 2, 11, 5])
+    o_out, o_pre, flags, noises, ver = oracle.denoise_trace(0, pcm, block=block)
+    assert (flags == 0).sum() > 4096 + 2000 and noises.shape[0] > 50
+    d = eng.denoiser(0, n_fft, block)
+    out, pre = d.process(pcm, want_precast=True)
+    check_stream(out, pre, o_out, o_pre)
+    assert np.array_equal(d.vad_trace(n_blocks, flags_only=True).astype(np.int32), flags)
+    assert np.abs(d.noise() - noises[-1]).max() <= TOL * noises[-1].max()
+    # (nearly) every block quiet: runs of hundreds of events, the average halving all the way
+    pcm = gen(78, 5000, pattern=[5000])
+    o_out, o_pre, flags, noises, ver = oracle.denoise_trace(1, pcm, block=block)
+    assert (flags == 0).mean() > 0.85
+    d2 = eng.denoiser(1, n_fft, block)
+    out, pre = d2.process(pcm, want_precast=True)
+    check_stream(out, pre, o_out, o_pre)
+    assert np.abs(d2.noise() - noises[-1]).max() <= TOL * noises[-1].max()
+    d.close()
+    d2.close()
+
+
+def test_small_calls_keep_the_sequential_average_bit_for_bit(eng):
+    """Up to 64 events per call the chunked average is the sequential one bit for bit (one event per chunk, one chunk
+    per group; a power-of-two factor commutes with rounding): per-block calls and a 60-block call agree exactly."""
+    n_blocks = 60
+    pcm = speechlike(9, n_blocks, pattern=[14, 2, 25, 3, 16])
+    a = eng.denoiser(0)
+    out_a, pre_a = a.process(pcm, want_precast=True)
+    b = eng.denoiser(0)
+    outs, pres = [], []
+    for j in range(n_blocks):
+        o, p = b.process(pcm[j * 512:(j + 1) * 512], want_precast=True)
+        outs.append(o)
+        pres.append(p)
+    assert np.array_equal(np.concatenate(outs), out_a)
+    assert np.array_equal(np.concatenate(pres), pre_a)
+    assert np.array_equal(a.noise(), b.noise())
+    a.close()
+    b.close()
