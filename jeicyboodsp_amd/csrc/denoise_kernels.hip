@@ -98,7 +98,7 @@ __global__ __launch_bounds__(64) void vad_kernel(const short *__restrict__ pcm, 
 //   * a lane's energy is clamped to 2^20 per four samples before the wave sum: the sum then fits 32 bits, and it
 //     exceeds 700 * n exactly when the true sum does (a clamped lane alone is already above the threshold);
 //   * the one 32-bit wave sum is five DPP adds (quad swaps, row mirrors, row broadcasts) and a v_readlane.
-// Flags are bit-identical to the traced kernel's (tests/test_denoise_gpu.py compares both with the oracle).
+// Flags are bit-identical to the traced kernel's (tests/test_denoise_gpu.py checks both against the CPU restatement).
 __device__ __forceinline__ unsigned int wave_sum_u32(unsigned int v)
 {
     v += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true);     // quad_perm [1,0,3,2]
