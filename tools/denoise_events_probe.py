@@ -50,10 +50,35 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--only-mode", type=int, default=-1)
+    ap.add_argument("--mvdr", action="store_true", help="the two MVDR chains instead (their VAD is the energy test alone)")
     a = ap.parse_args()
     eng = jeicyboodsp_amd.Engine(0)
     rng = np.random.default_rng(5)
     B = 65536
+    if a.mvdr:
+        for pause_frac, mean_run in ((0.0, 0), (0.1, 20), (0.5, 40), (1.0, 1 << 30)):
+            l, n_quiet = stream(rng, B, 512, pause_frac, mean_run)
+            r = np.roll(l, 3)
+            tl, tr = torch.from_numpy(l).cuda(), torch.from_numpy(r).cuda()
+            mv = eng.mvdr(0.0)
+            mv.process(tl, tr)
+            ms = timed(lambda: mv.process(tl, tr), a.iters)
+            print(json.dumps({"chain": "mvdr_2mic", "blocks": B, "pause_frac": pause_frac, "quiet_blocks": n_quiet,
+                              "us_per_call": round(ms * 1e3, 1)}), flush=True)
+            mv.close()
+        nb = 16384
+        for pause_frac, mean_run in ((0.0, 0), (0.01, 20), (0.1, 20)):
+            x, n_quiet = stream(rng, nb, 512, pause_frac, mean_run)
+            mics = np.stack([np.roll(x, 2 * m) for m in range(8)])
+            tm = torch.from_numpy(mics).cuda()
+            for n_fft in (1024, 512):
+                mv = eng.mvdr_multi(8, None, 1e-3, n_fft=n_fft)
+                mv.process(tm)
+                ms = timed(lambda: mv.process(tm), 3, rounds=3)
+                print(json.dumps({"chain": "mvdr_8mic", "n_fft": n_fft, "samples_per_mic": nb * 512, "pause_frac": pause_frac,
+                                  "quiet_1024pt_blocks": n_quiet, "us_per_call": round(ms * 1e3, 1)}), flush=True)
+                mv.close()
+        return
     for n_fft, block in ((1024, 512), (512, 256)):
         for pause_frac, mean_run in ((0.0, 0), (0.1, 20), (0.5, 40), (0.5, 6), (1.0, 1 << 30)):
             x, n_quiet = stream(rng, B, block, pause_frac, mean_run)
