@@ -136,6 +136,156 @@ __global__ __launch_bounds__(64) void fastconv1024_kernel(ConvStream s, long n_o
     }
 }
 
+// The same convolution with the spectrum kept in registers and every mirror pair of bins owned by one lane (frame_io.h,
+// PairTwiddles): five split / multiply / pre-split items per lane and filter instead of eight, no natural-order image,
+// no Z' image, and the kept samples leave straight from the inverse transform's registers -- lane l holds the sample
+// pair (2 l + 128 d, +1) in y[d], the output address of sample n is obase + n, and whichever of the two pairings
+// (n even | n odd first) is dword-aligned at this block's output address is stored as one dword per lane and register,
+// the odd pairing taking its second half from the next lane (DPP wave_shl:1; lane 63: lane 0's next register).  Waves
+// are persistent over blocks with the filters' 2 x 5 spectrum values per lane in registers.
+// H spectra are Hermitian (real taps), so Y[1024 - k] = conj(Y[k]) holds exactly as the pair scheme assumes.
+#ifndef JDSP_CONV1024_PAIRS
+#define JDSP_CONV1024_PAIRS 1
+#endif
+#ifndef JDSP_CONV1024_GRID
+#define JDSP_CONV1024_GRID (1024 * JDSP_CONV1024_MINWAVES)
+#endif
+// One register row of kept samples: lane l offers the pair (va, vb) = samples (na, na + 1), na = 2 l + 128 d + odd.  With
+// N0 / N1 known when the kernel is built a row is kept whole (one dword store per lane, the usual case), not at all, or
+// partly -- the rows holding the first and the last kept sample: per-lane tests there.  pc (tests only): pre-cast floats.
+template <int N0, int N1>
+__device__ __forceinline__ void constexpr_row(int d, int odd, short *obase, unsigned int *p32, float *pc, int lane,
+                                              float va, float vb)
+{
+    const int first = 128 * d + odd;                               // lane 0's na; d and odd are constants after unrolling
+    if (first + 128 <= N0 || first >= N1) return;
+    const int na = 2 * lane + first;
+    if (first >= N0 && first + 128 <= N1) {
+        __builtin_nontemporal_store(cast_i16_bits(va) | (cast_i16_bits(vb) << 16), p32 + 64 * d);
+        if (pc) { pc[na] = va; pc[na + 1] = vb; }
+        return;
+    }
+    const bool ka = na >= N0 && na < N1, kb = na + 1 >= N0 && na + 1 < N1;
+    if (ka && kb) p32[64 * d] = cast_i16_bits(va) | (cast_i16_bits(vb) << 16);
+    else if (ka) obase[na] = (short)cast_i16_bits(va);
+    else if (kb) obase[na + 1] = (short)cast_i16_bits(vb);
+    if (pc) {
+        if (ka) pc[na] = va;
+        if (kb) pc[na + 1] = vb;
+    }
+}
+
+// N0 = n_taps - 1, BLOCK: compile-time, so that which register rows are kept whole, partly or not at all is decided
+// when the kernel is built (instantiated for BASELINE config 2's 256 taps / 769-sample blocks; other shapes take
+// fastconv1024_kernel).
+#ifndef JDSP_CONV1024_H_IN_REGS
+#define JDSP_CONV1024_H_IN_REGS 1
+#endif
+#ifndef JDSP_CONV1024_MINWAVES
+#define JDSP_CONV1024_MINWAVES 3
+#endif
+template <int NF, int N0, int BLOCK>
+__global__ __launch_bounds__(64, JDSP_CONV1024_MINWAVES) void fastconv1024_pairs_kernel(ConvStream s, long n_out_blocks, int first_block,
+                                                                const float2 *__restrict__ Hall,
+                                                                const float2 *__restrict__ table, short *__restrict__ out,
+                                                                float *__restrict__ precast, long plane)
+{
+    __shared__ __attribute__((aligned(16))) float2 lds[kWaveLdsComplex];
+    const int lane = threadIdx.x;
+    if ((long)blockIdx.x >= n_out_blocks) return;
+    WaveTwiddles tw;
+    load_wave_twiddles(tw, table, lane);
+    PairTwiddles pw;
+    load_pair_twiddles(pw, table, lane);
+    constexpr int block = BLOCK, n0 = N0, n1 = N0 + BLOCK;       // samples [n0, n1) of every segment are kept (:156-158)
+    static_assert(n1 <= 1024, "segment of 1024 samples");
+#if JDSP_CONV1024_H_IN_REGS
+    float2 Hlo[NF][5], Hhi[NF][5];                              // the filters' spectrum values of this lane's ten bins
+#pragma unroll
+    for (int f = 0; f < NF; f++)
+#pragma unroll
+        for (int d = 0; d < 5; d++) {
+            Hlo[f][d] = Hall[(size_t)f * 1024 + lane + 64 * d];
+            Hhi[f][d] = Hall[(size_t)f * 1024 + lane + 64 * d + 512];
+        }
+#endif
+    // The launcher hands this kernel only blocks whose whole segment lies inside this call's buffer and past the stream's
+    // silent head (the others go to fastconv1024_kernel): plain loads, no per-sample tests.  A segment starts at a
+    // multiple of BLOCK samples, so its sample pairs are 2-byte-aligned dwords (the hardware takes them as they are);
+    // the next block's eight are requested before this block's arithmetic starts -- without that the wave spent 61 % of
+    // its time in s_waitcnt (profiles/r02_fastconv_pairs.txt).
+    typedef unsigned int u32_a2 __attribute__((aligned(2)));
+    unsigned int cur[8], nxt[8];
+    {
+        const short *src = s.pcm + ((long)(first_block + blockIdx.x + 1) * block - 1024) + 2 * lane;
+#pragma unroll
+        for (int r = 0; r < 8; r++) nxt[r] = *reinterpret_cast<const u32_a2 *>(src + 128 * r);
+    }
+    for (long e = blockIdx.x; e < n_out_blocks; e += gridDim.x) {
+#pragma unroll
+        for (int r = 0; r < 8; r++) cur[r] = nxt[r];
+        if (e + gridDim.x < n_out_blocks) {
+            const short *src = s.pcm + ((long)(first_block + e + gridDim.x + 1) * block - 1024) + 2 * lane;
+#pragma unroll
+            for (int r = 0; r < 8; r++) nxt[r] = *reinterpret_cast<const u32_a2 *>(src + 128 * r);
+        }
+        float2 v[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) v[r] = unpack_i16x2(cur[r]);
+        wave_fft512<false>(v, lds, lane, tw);
+        float2 zr[5], lo[5], hi[5];
+        wave_lds_fence();
+        pair_fetch_lds(v, lds, lane, zr);
+#pragma unroll
+        for (int d = 0; d < 5; d++) {
+            const float2 ev = cadd_conj(v[d], zr[d]);
+            const float2 od = csub_conj_mj(v[d], zr[d]);
+            const float2 p = cmul(pw.w[d], od);
+            lo[d] = cadd(ev, p);
+            hi[d] = csub(ev, p);
+        }
+#pragma unroll
+        for (int f = 0; f < NF; f++) {
+            float2 y[8], ret[4];
+#pragma unroll
+            for (int d = 0; d < 5; d++) {
+#if JDSP_CONV1024_H_IN_REGS
+                const float2 yl = cmul(lo[d], Hlo[f][d]), yh = cmul(hi[d], Hhi[f][d]);           // :150-151
+#else
+                const float2 *H = Hall + (size_t)f * 1024 + lane;         // 16 KB for a filter pair: L1 / L2 hits
+                const float2 yl = cmul(lo[d], H[64 * d]), yh = cmul(hi[d], H[64 * d + 512]);     // :150-151
+#endif
+                if (d < 4) presplit_inv_pair(yl, yh, pw.w[d], y[d], ret[d]);
+                else y[d] = presplit_inv_reg(yl, yh, pw.w[d]);
+            }
+            pair_return_lds(ret, lds, lane, y);
+            wave_fft512<true>(y, lds, lane, tw);
+            wave_lds_fence();
+            short *obase = out + (size_t)f * plane + e * block - n0;         // obase[n] = where sample n of the segment goes
+            const int odd = (int)((reinterpret_cast<uintptr_t>(obase) >> 1) & 1);  // wave-uniform: which pairing is dword-aligned
+            unsigned int *p32 = reinterpret_cast<unsigned int *>(obase + 2 * lane + odd);
+            float *pc = precast ? precast + (size_t)f * plane + e * block - n0 : nullptr;
+            if (!odd) {
+#pragma unroll
+                for (int d = 0; d < 8; d++) {
+                    constexpr_row<n0, n1>(d, 0, obase, p32, pc, lane, y[d].x, y[d].y);
+                }
+            } else {
+#pragma unroll
+                for (int d = 0; d < 8; d++) {
+                    // (y[n], y[n + 1]) for odd n = 2 lane + 1 + 128 d: the second half sits in the next lane's register
+                    int nx = __builtin_amdgcn_update_dpp(0, __float_as_int(y[d].x), 0x130, 0xf, 0xf, true);   // wave_shl:1
+                    if (d < 7) {
+                        const int first = __builtin_amdgcn_readfirstlane(__float_as_int(y[d < 7 ? d + 1 : d].x));
+                        nx = lane == 63 ? first : nx;
+                    }
+                    constexpr_row<n0, n1>(d, 1, obase, p32, pc, lane, y[d].y, __int_as_float(nx));
+                }
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // n_fft = 8192.  512 threads; thread t (wave w = t >> 6, lane l = t & 63).
 // 4096-point complex DFT of z[n], n = 512 n1 + n2, k = k1 + 8 k2:
@@ -277,7 +427,29 @@ int launch_fastconv(hipStream_t st, int n_fft, const ConvStream &s, long n_out_b
                     const float2 *tw8192, short *out, float *precast, long plane, short *hist_out)
 {
     if (n_out_blocks > 0) {
-        if (n_fft == 1024)
+        if (n_fft == 1024 && JDSP_CONV1024_PAIRS && (n_filters == 1 || n_filters == 2) && n_taps == 256 && block == 769) {
+            // blocks whose segment reaches before this call's buffer or into the stream's silent head (the first one or
+            // two of a call) take the general kernel; the rest the register-resident one, as persistent waves
+            long e_fast = 0;
+            const long lo_pos = s.valid_from - s.global0 > 0 ? s.valid_from - s.global0 : 0;
+            while (e_fast < n_out_blocks && (long)(first_block + e_fast + 1) * block - 1024 < lo_pos) e_fast++;
+            if (e_fast > 0)
+                hipLaunchKernelGGL(fastconv1024_kernel, dim3((unsigned)e_fast), dim3(64), 0, st, s, e_fast, first_block, block,
+                                   n_taps, n_filters, H, table, out, precast, plane);
+            const long n_fast = n_out_blocks - e_fast;
+            if (n_fast > 0) {
+                const unsigned grid = (unsigned)(n_fast < JDSP_CONV1024_GRID ? n_fast : JDSP_CONV1024_GRID);
+                short *out_f = out + e_fast * block;
+                float *pre_f = precast ? precast + e_fast * block : nullptr;
+                const int fb = first_block + (int)e_fast;
+                if (n_filters == 1)
+                    hipLaunchKernelGGL((fastconv1024_pairs_kernel<1, 255, 769>), dim3(grid), dim3(64), 0, st, s, n_fast, fb, H,
+                                       table, out_f, pre_f, plane);
+                else
+                    hipLaunchKernelGGL((fastconv1024_pairs_kernel<2, 255, 769>), dim3(grid), dim3(64), 0, st, s, n_fast, fb, H,
+                                       table, out_f, pre_f, plane);
+            }
+        } else if (n_fft == 1024)
             hipLaunchKernelGGL(fastconv1024_kernel, dim3((unsigned)n_out_blocks), dim3(64), 0, st, s, n_out_blocks,
                                first_block, block, n_taps, n_filters, H, table, out, precast, plane);
         else if (n_filters == 1)
