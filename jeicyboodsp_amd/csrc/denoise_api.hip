@@ -206,7 +206,7 @@ int jdsp_denoise_process_dev(jdsp_denoise *h, const int16_t *pcm_dev, long n_blo
                                       h->plan) ||
             jdsp::launch_noise_estimate512(s, pcm_dev, n_blocks, st_in, st_out, h->events, h->ev_n, h->plan,
                                            h->ver_base, h->snap_mask, ctx->stft1024_table, h->win512h, h->acc, h->rows) ||
-            jdsp::launch_denoise512(s, h->mode, pcm_dev, n_blocks, h->calls, st_in, st_out, h->ver_base, h->snap_mask,
+            jdsp::launch_denoise512(s, h->mode, ctx->n_cu, pcm_dev, n_blocks, h->calls, st_in, st_out, h->ver_base, h->snap_mask,
                                     h->rows, ctx->stft1024_table, h->win512h, out_dev, precast_dev))
             return fail(ctx, JDSP_EHIP, "denoise512 launch", hipGetLastError());
         h->cur ^= 1;

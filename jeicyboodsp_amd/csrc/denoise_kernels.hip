@@ -677,11 +677,11 @@ __device__ __forceinline__ void load_noise_pair_regs(NoisePairRegs &n, const flo
     for (int d = 0; d < 5; d++) { n.lo[d] = sc * row[lane + 64 * d]; n.hi[d] = sc * row[lane + 64 * d + 512]; }
 }
 
-// apply_gain<MODE>(x, n) / 1024 with n as load_noise_pair_regs left it
-template <int MODE>
+// apply_gain<MODE>(x, n) / 2^LOG2N (1024 or 512) with n as load_noise_pair_regs left it
+template <int MODE, int LOG2N = 10>
 __device__ __forceinline__ float2 apply_gain_scaled(float2 x, float n)
 {
-    const float c = 1.0f / 1024.0f;
+    const float c = 1.0f / (float)(1 << LOG2N);
     const float p = x.x * x.x + x.y * x.y;
     if (MODE == 0) {
         const float g = c - n * __frsqrt_rn(p);              // (|X| - N) / (1024 |X|); p == 0 gives inf / NaN, replaced below
@@ -1468,6 +1468,170 @@ __global__ __launch_bounds__(64, 3) void denoise512_kernel(
     }
 }
 
+// The same frames with the spectrum in registers and every mirror pair of bins owned by one lane (frame_io.h,
+// pair_fetch_lds / pair_return_lds): after the forward transform lane l works on k = l + 64 d, d < 5 -- A[k], B[k] from
+// Z[k] and Z[512 - k], ONE gain per frame and bin (N[512 - k] = N[k]: the estimate of a real frame's spectrum is
+// symmetric by construction, noise_accum512_kernel writes both from one value), Z'[k] = Ya + j Yb kept and
+// Z'[512 - k] = conj(Ya - j Yb) sent to its owner.  Ten gains per lane and frame pair instead of eighteen, no natural-
+// order image and no Y image; the wave is persistent over `run` consecutive blocks (run odd: pairs (j0 - 1, j0),
+// (j0 + 1, j0 + 2), ...), keeps both frames' noise values in registers until the estimate changes, and requests the
+// next pair's two new blocks before this pair's arithmetic.  The reference's 1/512 (SS:248) is folded into the gain.
+template <int MODE>
+__device__ __forceinline__ void load_noise512_regs(float (&n)[5], const float *__restrict__ row, int lane)
+{
+    const float sc = MODE == 0 ? (1.0f / 512.0f) : 1.0f;
+#pragma unroll
+    for (int d = 0; d < 5; d++) n[d] = sc * row[(lane + 64 * d) & 511];   // d = 4: bins 256..319 (bin k and 512 - k share a value)
+}
+
+// waves per SIMD: spectral subtraction fits 128 registers; Wiener with its NaN isolation does not (spills at 128:
+// 97 us against 89 us at three waves, profiles/r02_denoise512_run.txt)
+#define JDSP_DENOISE512_WAVES(MODE) ((MODE) == 0 ? 4 : 3)
+template <int MODE>
+__global__ __launch_bounds__(64, JDSP_DENOISE512_WAVES(MODE)) void denoise512_run_kernel(
+    const short *__restrict__ pcm, long n_blocks, long calls_before, const DenoiseState *__restrict__ st_in,
+    DenoiseState *st_out, const int *__restrict__ ver_base, const unsigned long long *__restrict__ snap_mask,
+    const float *__restrict__ noise_rows, const float2 *__restrict__ table, const float *__restrict__ win512,
+    short *__restrict__ out, float *__restrict__ precast, DenoiseShard sh, int run)
+{
+    __shared__ __attribute__((aligned(16))) float2 lds[kWaveLdsComplex];
+    const int lane = threadIdx.x;
+    const long per_xcd = (gridDim.x + 7) >> 3;                // XCD-aware run order (speed only)
+    const long j0 = ((long)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3)) * run;
+    if (j0 >= n_blocks) return;
+    const long j1 = j0 + run < n_blocks ? j0 + run : n_blocks;
+    const long n_samples = n_blocks * 256;
+    WaveTwiddles tw;
+    load_wave_twiddles(tw, table, lane);
+    float win[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) win[r] = win512[lane + 64 * r];
+
+    // blocks ja - 1, ja, ja + 1 of the current pair (ja, ja + 1), samples lane + 64 t of each
+    float xk[3][4], nx[2][4];
+#pragma unroll
+    for (int b = 0; b < 3; b++)
+#pragma unroll
+        for (int t = 0; t < 4; t++) xk[b][t] = dn512_sample(pcm, n_samples, st_in, (j0 - 2 + b) * 256 + lane + 64 * t);
+    float na[5], nb[5], tail[4];
+    const float *row_a = nullptr, *row_b = nullptr;
+    const long first_emit = sh.emit_from;
+    bool halo = true;                                         // frame j0 - 1 only rebuilds the overlap tail
+    for (long ja = j0 - 1; ja < j1; ja += 2) {
+        const long jb = ja + 1;
+        if (ja + 2 < j1) {                                    // the next pair's two new blocks, needed one iteration from now
+            if (ja + 2 >= 0 && ja + 4 <= n_blocks) {            // both inside this call's buffer (wave-uniform)
+                const short *src = pcm + (ja + 2) * 256 + lane;
+#pragma unroll
+                for (int t = 0; t < 4; t++) { nx[0][t] = (float)src[64 * t]; nx[1][t] = (float)src[256 + 64 * t]; }
+            } else {
+#pragma unroll
+                for (int b = 0; b < 2; b++)
+#pragma unroll
+                    for (int t = 0; t < 4; t++) nx[b][t] = dn512_sample(pcm, n_samples, st_in, (ja + 2 + b) * 256 + lane + 64 * t);
+            }
+        }
+        {
+            const float *ra = noise_row(noise_rows, ver_base, snap_mask, ja >= 0 ? ja : 0, sh);
+            const float *rb = noise_row(noise_rows, ver_base, snap_mask, jb < n_blocks ? jb : n_blocks - 1, sh);
+            if (ra != row_a) { row_a = ra; load_noise512_regs<MODE>(na, ra, lane); }     // wave-uniform: a new estimate was latched
+            if (rb != row_b) { row_b = rb; load_noise512_regs<MODE>(nb, rb, lane); }
+        }
+        float2 v[8], y[8];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            v[r] = make_float2(xk[0][r] * win[r], xk[1][r] * win[r]);
+            v[r + 4] = make_float2(xk[1][r] * win[r + 4], xk[2][r] * win[r + 4]);
+        }
+        wave_fft512<false>(v, lds, lane, tw);
+        float2 zr[5], ya[5], yb[5], ret[4];
+        wave_lds_fence();
+        pair_fetch_lds(v, lds, lane, zr);
+#pragma unroll
+        for (int d = 0; d < 5; d++) {
+            ya[d] = apply_gain_scaled<MODE, 9>(cadd_conj(v[d], zr[d]), na[d]);        // frame a, bin lane + 64 d
+            yb[d] = apply_gain_scaled<MODE, 9>(csub_conj_mj(v[d], zr[d]), nb[d]);     // frame b
+        }
+        // A frame with a non-finite bin (Wiener's 0/0 on an all-zero frame before any estimate, WF:204) has an all-NaN
+        // inverse transform in the reference.  Here it must not poison the frame it shares the transform with: its
+        // spectrum goes in as zero and its samples come out as NaN.
+        bool bad_a = false, bad_b = false;
+        if (MODE == 1) {
+            float ta = 0.f, tb = 0.f;                                 // NaN iff some bin is NaN or inf
+#pragma unroll
+            for (int d = 0; d < 5; d++) { ta += (ya[d].x + ya[d].y) * 0.f; tb += (yb[d].x + yb[d].y) * 0.f; }
+            bad_a = __ballot(ta != ta) != 0ull;
+            bad_b = __ballot(tb != tb) != 0ull;
+        }
+#pragma unroll
+        for (int d = 0; d < 5; d++) {
+            const float2 ak = bad_a ? make_float2(0.f, 0.f) : ya[d], bk = bad_b ? make_float2(0.f, 0.f) : yb[d];
+            y[d] = cadd_pj(ak, bk);                                   // Z'[k] = Ya[k] + j Yb[k]
+            if (d < 4) ret[d] = cconj_sub_j(ak, bk);                  // Z'[512 - k] = conj(Ya[k]) + j conj(Yb[k])
+        }
+        pair_return_lds(ret, lds, lane, y);
+        wave_fft512<true>(y, lds, lane, tw);
+        wave_lds_fence();
+        if (MODE == 1) {
+#pragma unroll
+            for (int d = 0; d < 8; d++) y[d] = make_float2(bad_a ? __builtin_nanf("") : y[d].x, bad_b ? __builtin_nanf("") : y[d].y);
+        }
+        // the very first call of a stream only stashes its block (SS:211-216): no transform, empty overlap
+        const bool a_void = calls_before + ja <= 0, b_void = calls_before + jb <= 0;
+        float oa[4], ob[4], tail_b[4];
+        if (halo) {
+            if (j0 == 0) {
+#pragma unroll
+                for (int d = 0; d < 4; d++) tail[d] = st_in->tail[lane + 64 * d];       // rgsdOveraped carried over
+            } else {
+#pragma unroll
+                for (int d = 0; d < 4; d++) tail[d] = a_void ? 0.f : y[d + 4].x;
+            }
+        } else {
+#pragma unroll
+            for (int d = 0; d < 4; d++) {
+                oa[d] = tail[d] + (a_void ? 0.f : y[d].x);                              // SS:248 overlap-add
+                tail[d] = a_void ? 0.f : y[d + 4].x;                                    // SS:255-256
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+            ob[d] = tail[d] + (b_void ? 0.f : y[d].y);
+            tail_b[d] = b_void ? 0.f : y[d + 4].y;
+        }
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            const long j = half ? jb : ja;
+            if ((half == 0 && halo) || j >= n_blocks) continue;
+            const float *o = half ? ob : oa;
+            if (j >= first_emit && j < sh.emit_to) {
+                const long oi = j - first_emit;
+#pragma unroll
+                for (int d = 0; d < 4; d++) out[oi * 256 + lane + 64 * d] = (short)cast_i16_bits(o[d]);
+                if (precast) {
+#pragma unroll
+                    for (int d = 0; d < 4; d++) precast[oi * 256 + lane + 64 * d] = o[d];
+                }
+            }
+            if (j == n_blocks - 1) {                                                    // SS:257 and the overlap carried out
+#pragma unroll
+                for (int d = 0; d < 4; d++) {
+                    st_out->prev[lane + 64 * d] = pcm[j * 256 + lane + 64 * d];
+                    st_out->tail[lane + 64 * d] = half ? tail_b[d] : tail[d];
+                }
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+            tail[d] = tail_b[d];
+            xk[0][d] = xk[2][d];
+            xk[1][d] = nx[0][d];
+            xk[2][d] = nx[1][d];
+        }
+        halo = false;
+    }
+}
+
 int launch_noise_estimate512(hipStream_t s, const short *pcm, long n_blocks, const DenoiseState *st_in,
                              DenoiseState *st_out, const int *events, const int *ev_n, const DenoisePlan *plan,
                              const int *ver_base, const unsigned long long *snap_mask, const float2 *table,
@@ -1482,7 +1646,7 @@ int launch_noise_estimate512(hipStream_t s, const short *pcm, long n_blocks, con
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
-int launch_denoise512(hipStream_t s, int mode, const short *pcm, long n_blocks, long calls_before,
+int launch_denoise512(hipStream_t s, int mode, int n_cu, const short *pcm, long n_blocks, long calls_before,
                       const DenoiseState *st_in, DenoiseState *st_out, const int *ver_base,
                       const unsigned long long *snap_mask, const float *noise_rows, const float2 *table,
                       const float *win512, short *out, float *precast)
@@ -1493,6 +1657,25 @@ int launch_denoise512(hipStream_t s, int mode, const short *pcm, long n_blocks, 
     sh.ver_row_off = nullptr;
     sh.emit_from = calls_before >= 2 ? 0 : 2 - calls_before;
     sh.emit_to = n_blocks;
+#ifndef JDSP_DENOISE512_RUN
+#define JDSP_DENOISE512_RUN 1
+#endif
+    if (JDSP_DENOISE512_RUN) {
+        // one round of resident waves (4 per SIMD); an odd number of blocks per wave, 7 at least
+        const long slots = (long)(n_cu > 0 ? n_cu : 256) * 4 * JDSP_DENOISE512_WAVES(mode);
+        long run = (n_blocks + slots - 1) / slots;
+        if (run < 7) run = 7;
+        run |= 1;
+        const long waves = (n_blocks + run - 1) / run;
+        const long grid = (waves + 7) / 8 * 8;
+        if (mode == 0)
+            hipLaunchKernelGGL(denoise512_run_kernel<0>, dim3((unsigned)grid), dim3(64), 0, s, pcm, n_blocks, calls_before, st_in,
+                               st_out, ver_base, snap_mask, noise_rows, table, win512, out, precast, sh, (int)run);
+        else
+            hipLaunchKernelGGL(denoise512_run_kernel<1>, dim3((unsigned)grid), dim3(64), 0, s, pcm, n_blocks, calls_before, st_in,
+                               st_out, ver_base, snap_mask, noise_rows, table, win512, out, precast, sh, (int)run);
+        return hipGetLastError() == hipSuccess ? 0 : -1;
+    }
     const long waves = (n_blocks + kDn512BlocksPerWave - 1) / kDn512BlocksPerWave;
     const long grid = (waves + 7) / 8 * 8;
     if (mode == 0)

@@ -136,7 +136,7 @@ int launch_noise_estimate512(hipStream_t s, const short *pcm, long n_blocks, con
                              DenoiseState *st_out, const int *events, const int *ev_n, const DenoisePlan *plan,
                              const int *ver_base, const unsigned long long *snap_mask, const float2 *table,
                              const float *win512, const NoiseAccum &acc, float *noise_rows);
-int launch_denoise512(hipStream_t s, int mode, const short *pcm, long n_blocks, long calls_before,
+int launch_denoise512(hipStream_t s, int mode, int n_cu, const short *pcm, long n_blocks, long calls_before,
                       const DenoiseState *st_in, DenoiseState *st_out, const int *ver_base,
                       const unsigned long long *snap_mask, const float *noise_rows, const float2 *table,
                       const float *win512, short *out, float *precast);
