@@ -231,7 +231,7 @@ int launch_hmm_viterbi(hipStream_t stream, const double *feats, long n_frames, c
                        const double *gmm, const double *log_trans, int n_models, int fused, double log_init, double *b,
                        double *scores, int *best, int *path, double *trellis);
 int launch_mfcc(hipStream_t s, const short *pcm, const long long *starts, long n_frames, const MfccDev &p,
-                const float2 *table, double *feats);
+                const float2 *table, double *feats, int *redo);
 
 }  // namespace jdsp
 
@@ -272,6 +272,8 @@ struct jdsp_mfcc {
     jdsp_mfcc_cfg cfg;
     jdsp::MfccDev dev;
     void *blob = nullptr;                 // one device allocation holding every table
+    int *redo = nullptr;                  // 512-FFT configurations: {count, frame pairs to recompute apart} (mfcc512_run_kernel)
+    long redo_cap = 0;                    // pairs it holds
     std::vector<double> mel_freqs, fbank;
     std::vector<int> fi_bins;
     // FP64 tables of the separately callable sub-steps (stage_api.hip), built on first use

@@ -134,6 +134,7 @@ int jdsp_mfcc_destroy(jdsp_mfcc *h)
     (void)hipSetDevice(h->ctx->device);
     (void)hipStreamSynchronize(h->ctx->stream);
     if (h->blob) (void)hipFree(h->blob);
+    if (h->redo) (void)hipFree(h->redo);
     if (h->stage_blob) (void)hipFree(h->stage_blob);
     delete h;
     return JDSP_OK;
@@ -156,8 +157,16 @@ int jdsp_mfcc_frames_dev(jdsp_mfcc *h, const int16_t *pcm_dev, const int64_t *fr
     if (n_frames < 0 || (n_frames > 0 && (!pcm_dev || !feats_dev))) return fail(ctx, JDSP_EINVAL, "jdsp_mfcc_frames: bad buffer");
     if (n_frames == 0) return JDSP_OK;
     JDSP_HIP(ctx, hipSetDevice(ctx->device));
+    if (h->dev.bin_stride == 2 && (n_frames + 1) / 2 > h->redo_cap) {        // no-op once sized (size it before a graph capture)
+        JDSP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (h->redo) (void)hipFree(h->redo);
+        h->redo = nullptr;
+        h->redo_cap = 0;
+        JDSP_HIP(ctx, hipMalloc((void **)&h->redo, ((size_t)(n_frames + 1) / 2 + 1) * sizeof(int)));
+        h->redo_cap = (n_frames + 1) / 2;
+    }
     if (jdsp::launch_mfcc(ctx->stream, pcm_dev, (const long long *)frame_start_dev, n_frames, h->dev, ctx->stft1024_table,
-                          feats_dev))
+                          feats_dev, h->redo))
         return fail(ctx, JDSP_EHIP, "mfcc launch", hipGetLastError());
     return JDSP_OK;
 }

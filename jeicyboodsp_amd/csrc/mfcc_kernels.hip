@@ -11,17 +11,26 @@
 
 namespace jdsp {
 
+// redo (or NULL): {count, pair indices...} left by mfcc512_run_kernel -- the frames 2 q and 2 q + 1 of every listed pair
+// are computed again here, each in a transform of its own, by waves that stride over the list.
 __global__ __launch_bounds__(64) void mfcc_kernel(const short *__restrict__ pcm, const long long *__restrict__ starts,
                                                   long n_frames, MfccDev p, const float2 *__restrict__ table,
-                                                  double *__restrict__ feats)
+                                                  double *__restrict__ feats, const int *__restrict__ redo)
 {
     __shared__ __attribute__((aligned(16))) float2 lds[kWaveLdsComplex];
     __shared__ float mag[512];
     __shared__ float logmel[64];
     const int lane = threadIdx.x;
     const long per_xcd = (gridDim.x + 7) >> 3;
-    const long f = (long)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    if (f >= n_frames) return;
+    long f = (long)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    long it = blockIdx.x;
+  for (;;) {
+    if (redo) {
+        if (it >= 2L * redo[0]) return;
+        f = 2L * redo[1 + (it >> 1)] + (it & 1);
+        it += gridDim.x;
+        if (f >= n_frames) continue;
+    } else if (f >= n_frames) return;
     const short *src = pcm + (starts ? starts[f] : (long long)p.hop * f);
 
     WaveTwiddles tw;
@@ -135,6 +144,9 @@ __global__ __launch_bounds__(64) void mfcc_kernel(const short *__restrict__ pcm,
         acc += __shfl_xor(acc, 32);
         if (lane < p.n_cep) feats[f * p.n_cep + lane] = acc * p.lifter_w[lane];
     }
+    if (!redo) return;
+    wave_lds_fence();
+  }
 }
 
 
@@ -352,19 +364,224 @@ __global__ __launch_bounds__(64) void mfcc_x2_kernel(const short *__restrict__ p
     }
 }
 
+// ---- persistent waves, spectrum in registers ------------------------------------------------------------------------
+// mfcc_x2_kernel reloads ~64 table values per wave (twiddles, window, filterbank pieces) for its two frames and spends
+// 44 % of its wave cycles in s_waitcnt; the kernels below keep the tables in registers over a grid-stride loop of frame
+// pairs, request the next pair's samples before this pair's arithmetic, take |X| from registers (frame_io.h: mirror
+// operands by pair_fetch_lds, no natural-order image) and share mfcc_x2_kernel's filterbank / ln / DCT / lifter tail.
+struct MelPiece { int4 sg; float sw[16], cw[16]; };
+
+__device__ __forceinline__ void load_mel_piece(MelPiece &m, const MfccDev &p, int lane)
+{
+    m.sg = p.seg[lane];
+#pragma unroll
+    for (int t = 0; t < 16; t++) { m.sw[t] = p.seg_w[t * 64 + lane]; m.cw[t] = p.seg_c[t * 64 + lane]; }
+}
+
+// |X| of two frames, bin i at mag[i + (i >> 4)] (see mfcc_x2_kernel) -> feats[fa], feats[fb]
+__device__ __forceinline__ void mfcc_tail_x2(const float *mag_a, const float *mag_b, float (*logmel)[64], const MfccDev &p,
+                                             int lane, const MelPiece &mp, long fa, long fb, bool two, double *__restrict__ feats)
+{
+    {
+        float lo_a = 0.f, hi_a = 0.f, lo_b = 0.f, hi_b = 0.f;
+        float ma[16], mb[16];
+        const int last = p.n_bins - 1;
+#pragma unroll
+        for (int t = 0; t < 16; t++) {                               // all thirty-two reads in flight together
+            const int bin = min(mp.sg.x + t, last);                  // past the piece: a finite value, its weights are 0
+            const int q = bin + (bin >> 4);
+            ma[t] = mag_a[q];
+            mb[t] = mag_b[q];
+        }
+#pragma unroll
+        for (int t = 0; t < 16; t++) {
+            lo_a = fmaf(mp.sw[t], ma[t], lo_a); hi_a = fmaf(mp.cw[t], ma[t], hi_a);   // :164 / :161,:165-166
+            lo_b = fmaf(mp.sw[t], mb[t], lo_b); hi_b = fmaf(mp.cw[t], mb[t], hi_b);
+        }
+        if (mp.sg.y > 0) {
+            if (mp.sg.z >= 1) { atomicAdd(&logmel[0][mp.sg.z - 1], lo_a); atomicAdd(&logmel[1][mp.sg.z - 1], lo_b); }
+            if (mp.sg.z < p.n_chan) { atomicAdd(&logmel[0][mp.sg.z], hi_a); atomicAdd(&logmel[1][mp.sg.z], hi_b); }
+        }
+    }
+    wave_lds_fence();
+    if (lane < p.n_chan) {                                           // :171, hardware log2 (see mfcc_x2_kernel)
+        logmel[0][lane] = __logf(logmel[0][lane]);
+        logmel[1][lane] = __logf(logmel[1][lane]);
+    }
+    wave_lds_fence();
+    const bool wide = p.n_cep > 16;                                  // DCT-II (:178-182) and lifter (:189), see mfcc_kernel
+    const int i = wide ? (lane & 31) : (lane & 15), part = wide ? (lane >> 5) : (lane >> 4), step = wide ? 2 : 4;
+    double acc_a = 0.0, acc_b = 0.0;
+    if (i < p.n_cep) {
+#pragma unroll 4
+        for (int k = part; k < p.n_chan; k += step) {
+            const double c = p.dct[k * 32 + i];
+            acc_a += c * (double)logmel[0][k];
+            acc_b += c * (double)logmel[1][k];
+        }
+    }
+    if (!wide) { acc_a = sum_xor16_f64(acc_a); acc_b = sum_xor16_f64(acc_b); }
+    acc_a = sum_xor32_f64(acc_a); acc_b = sum_xor32_f64(acc_b);
+    if (lane < p.n_cep) {
+        const double lw = p.lifter_w[lane];
+        feats[fa * p.n_cep + lane] = acc_a * lw;
+        if (two) feats[fb * p.n_cep + lane] = acc_b * lw;
+    }
+    wave_lds_fence();                                                // logmel and the magnitudes are rewritten next
+}
+
+// sum over the wave, the same value in every lane's copy of lane 63 (five DPP adds and a v_readlane; a __shfl_xor tree
+// is six ds_bpermute, 8.9 issue slots each)
+__device__ __forceinline__ float wave_sum_f32(float v)
+{
+#define JDSP_DPP_ADD(CTRL, ROWS) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROWS, 0xf, true))
+    JDSP_DPP_ADD(0xB1, 0xf);     // quad_perm [1,0,3,2]
+    JDSP_DPP_ADD(0x4E, 0xf);     // quad_perm [2,3,0,1]
+    JDSP_DPP_ADD(0x141, 0xf);    // row_half_mirror: sums of 8
+    JDSP_DPP_ADD(0x140, 0xf);    // row_mirror: sums of 16
+    JDSP_DPP_ADD(0x142, 0xa);    // row_bcast15 into rows 1 and 3
+    JDSP_DPP_ADD(0x143, 0xc);    // row_bcast31 into rows 2 and 3
+#undef JDSP_DPP_ADD
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+// previous lane's value (wave_shr:1); lane 0 gets `lane0`
+__device__ __forceinline__ float prev_lane(float v, float lane0, int lane)
+{
+    const int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, true);
+    return lane == 0 ? lane0 : __int_as_float(t);
+}
+
+// Two frames' samples (lane + 64 r) -> pre-emphasis (:208-210), window, one transform, |A[k]|, |B[k]| for k = lane + 64 d,
+// d < 4.  Returns whether the two frames' energies are more than 36 dB apart (wave-uniform).
+__device__ __forceinline__ bool mfcc512_pair_mags(const float (&sa)[8], const float (&sb)[8], float preemph,
+                                                  const float (&win)[8], const WaveTwiddles &tw, float2 *lds, int lane,
+                                                  float (&ma)[4], float (&mb)[4])
+{
+    // x[i] = s[i] - preemph * s[i-1] for 1 <= i < win_len, x[0] = 0 (:208 starts at i = 1); the window is zero beyond
+    float2 v[8];
+    float ea = 0.f, eb = 0.f;
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const float pa = prev_lane(sa[r], r > 0 ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sa[r > 0 ? r - 1 : 0]), 63)) : 0.f, lane);
+        const float pb = prev_lane(sb[r], r > 0 ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sb[r > 0 ? r - 1 : 0]), 63)) : 0.f, lane);
+        float xa = (sa[r] - preemph * pa) * win[r], xb = (sb[r] - preemph * pb) * win[r];
+        if (r == 0 && lane == 0) { xa = 0.f; xb = 0.f; }
+        ea = fmaf(xa, xa, ea);
+        eb = fmaf(xb, xb, eb);
+        v[r] = make_float2(xa, xb);
+    }
+    ea = wave_sum_f32(ea);
+    eb = wave_sum_f32(eb);
+    wave_fft512<false>(v, lds, lane, tw);
+    wave_lds_fence();
+    // bins k = lane + 64 d, d < 4 (0..255): mirrors Z[512 - k] are registers 4..7 of other lanes and Z[512] = Z[0]
+#pragma unroll
+    for (int d = 4; d < 8; d++) lds[lane + 64 * d] = v[d];
+    if (lane == 0) lds[512] = v[0];
+    wave_lds_fence();
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+        const float2 zm = lds[512 - lane - 64 * d];
+        const float2 A = cadd_conj(v[d], zm), B = csub_conj_mj(v[d], zm);
+        ma[d] = __builtin_amdgcn_sqrtf(A.x * A.x + A.y * A.y);   // hardware square root, 1 ulp (see mfcc_kernel)
+        mb[d] = __builtin_amdgcn_sqrtf(B.x * B.x + B.y * B.y);
+    }
+    wave_lds_fence();
+    return !(ea <= 4096.f * eb && eb <= 4096.f * ea);            // also when exactly one frame is all zeros
+}
+
+#ifndef JDSP_MFCC512_WAVES
+#define JDSP_MFCC512_WAVES 3
+#endif
+// n_fft = 512 (BASELINE config 4: 400-sample window, 512-FFT): TWO frames per 512-point transform, z[n] = a[n] + j b[n],
+// A[k] = (Z[k] + conj Z[512-k]) / 2, B[k] = -j (Z[k] - conj Z[512-k]) / 2 (the 1/2 is in the window table) -- half the
+// transform work of the zero-padded 1024-point form mfcc_x2_kernel uses for this configuration.  Lane l holds sample
+// l + 64 r of both frames (2-byte loads: any frame start), the sample before it comes from lane l - 1.
+// The two spectra come apart exactly only in exact arithmetic: frame b's rounding (6e-8 of ITS magnitudes) lands in
+// frame a's bins.  Between neighbours of similar level that is the FP32 noise floor the 1e-5 bar already allows for;
+// when the two frames' energies differ by more than 36 dB (or one of them is all zeros, whose ln 0 = -inf, :171, must
+// stay exact) the pair's index goes onto a list and mfcc_kernel computes both frames again, one per transform (a branch
+// inside this kernel cost 15 % of its speed in registers: profiles/r02_mfcc512_run.txt).
+__global__ __launch_bounds__(64, JDSP_MFCC512_WAVES) void mfcc512_run_kernel(const short *__restrict__ pcm, const long long *__restrict__ starts,
+                                                            long n_frames, MfccDev p, const float2 *__restrict__ table,
+                                                            double *__restrict__ feats, int *__restrict__ redo)
+{
+    __shared__ __attribute__((aligned(16))) float2 lds[kWaveLdsComplex];
+    __shared__ float logmel[2][64];
+    const int lane = threadIdx.x;
+    const long n_pairs = (n_frames + 1) >> 1;
+    if ((long)blockIdx.x >= n_pairs) return;
+    WaveTwiddles tw;
+    load_wave_twiddles(tw, table, lane);
+    float win[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) win[r] = reinterpret_cast<const float *>(p.window)[lane + 64 * r];   // zero from win_len on
+    MelPiece mp;
+    load_mel_piece(mp, p, lane);
+    const int rows = (p.win_len + 63) >> 6;                          // register rows that hold samples (wave-uniform)
+    float na[8], nb[8];                                              // the next pair's samples
+    auto fetch = [&](long q) {
+        const long fa = 2 * q, fb = fa + 1 < n_frames ? fa + 1 : fa;
+        const short *sa = pcm + (starts ? starts[fa] : (long long)p.hop * fa) + lane;
+        const short *sb = pcm + (starts ? starts[fb] : (long long)p.hop * fb) + lane;
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const bool in = r < rows - 1 || (r == rows - 1 && lane + 64 * r < p.win_len);
+            na[r] = in ? (float)sa[64 * r] : 0.f;
+            nb[r] = in ? (float)sb[64 * r] : 0.f;
+        }
+    };
+    fetch(blockIdx.x);
+    for (long q = blockIdx.x; q < n_pairs; q += gridDim.x) {
+        const long fa = 2 * q;
+        const bool two = fa + 1 < n_frames;
+        const long fb = two ? fa + 1 : fa;                           // odd tail: the second slot repeats the first
+        float sa[8], sb[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) { sa[r] = na[r]; sb[r] = nb[r]; }
+        if (q + gridDim.x < n_pairs) fetch(q + gridDim.x);
+        float ma[4], mb[4];
+        if (mfcc512_pair_mags(sa, sb, p.preemph, win, tw, lds, lane, ma, mb) && lane == 0)
+            redo[1 + atomicAdd(redo, 1)] = (int)q;                   // rare: both frames again, apart (mfcc_kernel)
+        float *mag_a = reinterpret_cast<float *>(lds), *mag_b = mag_a + 320;
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+            const int k = lane + 64 * d, qk = k + (k >> 4);
+            mag_a[qk] = ma[d];
+            mag_b[qk] = mb[d];
+        }
+        logmel[0][lane] = 0.f;
+        logmel[1][lane] = 0.f;
+        wave_lds_fence();
+        mfcc_tail_x2(mag_a, mag_b, logmel, p, lane, mp, fa, fb, two, feats);
+    }
+}
+
 int launch_mfcc(hipStream_t s, const short *pcm, const long long *starts, long n_frames, const MfccDev &p,
-                const float2 *table, double *feats)
+                const float2 *table, double *feats, int *redo)
 {
     if (n_frames <= 0) return 0;
 #ifndef JDSP_MFCC_X2
 #define JDSP_MFCC_X2 1             // 1: two frames per wavefront in lock-step (mfcc_x2_kernel); 0: one frame per wavefront
 #endif
-    if (JDSP_MFCC_X2 && p.seg_ok) {
+#ifndef JDSP_MFCC_RUN
+#define JDSP_MFCC_RUN 1            // 1: persistent register-resident kernels where they apply
+#endif
+    if (JDSP_MFCC_RUN && p.seg_ok && p.bin_stride == 2 && p.win_len <= 512 && redo) {
+        const long n_pairs = (n_frames + 1) / 2;
+        if (hipMemsetAsync(redo, 0, sizeof(int), s) != hipSuccess) return -1;
+        const long slots = 1024L * JDSP_MFCC512_WAVES;              // resident waves of a 256-CU part
+        const long grid = n_pairs < slots ? n_pairs : slots;
+        hipLaunchKernelGGL(mfcc512_run_kernel, dim3((unsigned)grid), dim3(64), 0, s, pcm, starts, n_frames, p, table, feats, redo);
+        hipLaunchKernelGGL(mfcc_kernel, dim3(1024), dim3(64), 0, s, pcm, starts, n_frames, p, table, feats, (const int *)redo);
+    } else if (JDSP_MFCC_X2 && p.seg_ok) {
         const long grid = ((n_frames + 1) / 2 + 7) / 8 * 8;
         hipLaunchKernelGGL(mfcc_x2_kernel, dim3((unsigned)grid), dim3(64), 0, s, pcm, starts, n_frames, p, table, feats);
     } else {                              // filterbanks that do not fit one piece per lane (many narrow channels)
         const long grid = (n_frames + 7) / 8 * 8;
-        hipLaunchKernelGGL(mfcc_kernel, dim3((unsigned)grid), dim3(64), 0, s, pcm, starts, n_frames, p, table, feats);
+        hipLaunchKernelGGL(mfcc_kernel, dim3((unsigned)grid), dim3(64), 0, s, pcm, starts, n_frames, p, table, feats,
+                           (const int *)nullptr);
     }
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }

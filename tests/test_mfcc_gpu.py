@@ -166,10 +166,36 @@ def test_baseline_config4_ten_thousand_ragged_utterances(eng, oracle):
         got = feats[first[u]:first[u + 1]].cpu().numpy()
         want = oracle.mfcc_frames(ocfg, pcm[offs[u]:offs[u + 1]], int(nf[u]))
         _check(got, want)
-    # an utterance's vectors do not depend on its neighbours: recompute one alone through the host entry
+    # an utterance's vectors do not depend on its neighbours beyond rounding: recomputed alone through the host entry
+    # its frames pair up differently inside the shared transforms (mfcc512_run_kernel: two frames per transform), which
+    # moves results by FP32 rounding only
     u = pick[len(pick) // 2]
     alone = m.frames(pcm[offs[u]:offs[u + 1]])
-    assert np.array_equal(alone, feats[first[u]:first[u + 1]].cpu().numpy())
+    batch = feats[first[u]:first[u + 1]].cpu().numpy()
+    assert (np.abs(alone - batch) / np.abs(batch).max(axis=1, keepdims=True)).max() < 2e-6
+    m.close()
+
+
+def test_paired_frames_of_very_different_level_and_silence(eng, oracle):
+    """512-FFT configurations put two frames into one transform.  A loud frame's rounding must not show in a quiet
+    partner (more than 36 dB apart: separate passes), and an all-zero frame keeps the reference's ln 0 = -inf whatever
+    it is paired with."""
+    kw = dict(win_len=400, hop=160, n_fft=512, n_chan=40, n_cep=13, half_rate=8000.0)
+    ocfg = oracle.mfcc_cfg(n_bins=256, **kw)
+    rng = np.random.default_rng(31)
+    n = 400 + 160 * 39
+    pcm = np.rint(rng.normal(0, 2.0, n)).astype(np.int16)                   # a few LSB of noise ...
+    pcm[160 * 20 + 240:] = np.clip(np.rint(rng.normal(0, 9000, n - 160 * 20 - 240)), -32768, 32767).astype(np.int16)   # ... then 73 dB louder
+    pcm[160 * 4:160 * 4 + 400 + 160] = 0                                    # frames 4 and 5 all zero; 3 and 6 partly
+    m = eng.mfcc(**kw)
+    for first_frame in (0, 1):                                              # both pairings of every neighbour
+        x = pcm[160 * first_frame:]
+        nf = (x.size - 400) // 160 + 1
+        got = m.frames(x)
+        want = oracle.mfcc_frames(ocfg, x, nf)
+        fin = np.isfinite(want).all(axis=1)
+        assert np.array_equal(np.isfinite(got).all(axis=1), fin) and (~fin).sum() == 2
+        _check(got[fin], want[fin])
     m.close()
 
 
