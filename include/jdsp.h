@@ -136,6 +136,13 @@ int jdsp_stft_i16_dev(jdsp_ctx *ctx, const int16_t *pcm_dev, long n_frames,
 int jdsp_stft_half_i16_dev(jdsp_ctx *ctx, const int16_t *pcm_dev, long n_frames, jdsp_c32 *spec_dev, long row_pitch);
 int jdsp_stft_i16(jdsp_ctx *ctx, const int16_t *pcm_host, long n_samples,
                   int n_fft, int hop, jdsp_c32 *spec_host, long *n_frames_out);
+/* The same analysis in the reference's own precision (SS:218-230 computes in double): FP64 window, FP64 transform,
+ * spec = n_frames x 1024 interleaved (re, im) doubles (16,384 B per frame).  n_fft = 1024, any hop >= 1.  Agrees with
+ * the reference's FFTProcess on the same windowed frames to ~1e-11 of the frame peak (FFTProcess's truncated PI,
+ * FFT:15); the FP32 entries above agree with this one to ~5e-7. */
+int jdsp_stft_i16_f64_dev(jdsp_ctx *ctx, const int16_t *pcm_dev, long n_frames, int n_fft, int hop, double *spec_dev);
+int jdsp_stft_i16_f64(jdsp_ctx *ctx, const int16_t *pcm_host, long n_samples, int n_fft, int hop, double *spec_host,
+                      long *n_frames_out);
 
 /* ---- spectral subtraction / Wiener filter ------------------------------------- */
 /* One jdsp_denoise object holds everything the reference keeps in static locals

@@ -137,6 +137,8 @@ def _load():
         "jdsp_stft_half_i16_dev": (i, [vp, vp, l, vp, l]),
         "jdsp_stft_i16_dev": (i, [vp, vp, l, i, i, vp]),
         "jdsp_stft_i16": (i, [vp, vp, l, i, i, vp, C.POINTER(l)]),
+        "jdsp_stft_i16_f64_dev": (i, [vp, vp, l, i, i, vp]),
+        "jdsp_stft_i16_f64": (i, [vp, vp, l, i, i, vp, C.POINTER(l)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)

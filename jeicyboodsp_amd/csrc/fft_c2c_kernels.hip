@@ -227,6 +227,101 @@ int launch_bitrev_table(hipStream_t stream, short *table_dev, int n_fft, int bit
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
+// ---- STFT analysis in the reference's own precision ---------------------------------------------------------
+// SS:218-230 for n_frames frames with every operation in FP64: frame f = pcm[hop f .. hop f + 1024) x Hamming (the
+// reference's own doubles, PI 3.141592), the 1024-point real transform as a 512-point complex one of
+// z[n] = x[2n] + j x[2n+1] (the radix-8 passes of fft512_f64_kernel) and the split
+//     E = Z[m] + conj Z[512-m],  O = -j (Z[m] - conj Z[512-m]),  X[m] = (E + W^m O) / 2,  X[m+512] = (E - W^m O) / 2,
+// all 1024 bins out as complex128: 2 KB in, 16 KB out per frame -- an HBM-bound kernel like the FP32 one, at twice
+// its bytes.  table: [0, 1024) window as doubles, then 512 double2 W^m = exp(-2 pi j m / 1024).
+__global__ __launch_bounds__(64) void stft1024_f64_kernel(const short *__restrict__ pcm, long n_frames, long hop,
+                                                          const double *__restrict__ table, const double2 *__restrict__ tw,
+                                                          double2 *__restrict__ out)
+{
+    __shared__ __attribute__((aligned(16))) cd lds[kFft512Lds];
+    const int lane = threadIdx.x;
+    const long per_xcd = (gridDim.x + 7) >> 3;            // XCD-aware order: neighbouring frames share an XCD's L2
+    const long t = (long)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (t >= n_frames) return;
+    const short *src = pcm + t * hop + 2 * lane;
+    const double2 *win = reinterpret_cast<const double2 *>(table) + lane;
+    const double2 *wsp = reinterpret_cast<const double2 *>(table + 1024) + lane;
+    cd v[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const double2 w = win[64 * r];
+        v[r] = {(double)src[128 * r] * w.x, (double)src[128 * r + 1] * w.y};
+    }
+    cd_dft8<false>(v);
+#pragma unroll
+    for (int k = 1; k < 8; k++) v[k] = cd_mul(v[k], w512<false>(tw, lane * k));
+#pragma unroll
+    for (int k = 0; k < 8; k++) lds[k * 72 + lane] = v[k];
+    lds_fence_wave();
+    {
+        const int base = (lane >> 3) * 72 + (lane & 7);
+#pragma unroll
+        for (int a = 0; a < 8; a++) v[a] = lds[base + 8 * a];
+    }
+    lds_fence_wave();
+    cd_dft8<false>(v);
+#pragma unroll
+    for (int c = 1; c < 8; c++) v[c] = cd_mul(v[c], w512<false>(tw, 8 * (lane & 7) * c));
+    {
+        const int base = (lane >> 3) * 73 + (lane & 7);
+#pragma unroll
+        for (int c = 0; c < 8; c++) lds[base + 8 * c] = v[c];
+    }
+    lds_fence_wave();
+    {
+        const int base = (lane & 7) * 73 + (lane >> 3) * 8;
+#pragma unroll
+        for (int b = 0; b < 8; b++) v[b] = lds[base + b];
+    }
+    lds_fence_wave();
+    cd_dft8<false>(v);                                   // v[d] = Z[lane + 64 d]
+    // natural-order image (slot 512 = Z[0]) for the mirrored operands
+#pragma unroll
+    for (int d = 0; d < 8; d++) lds[lane + 64 * d] = v[d];
+    if (lane == 0) lds[512] = v[0];
+    lds_fence_wave();
+    typedef double f64x2 __attribute__((ext_vector_type(2)));
+    f64x2 *dst = reinterpret_cast<f64x2 *>(out + t * 1024 + lane);
+#pragma unroll
+    for (int d = 0; d < 8; d++) {
+        const cd zm = lds[512 - lane - 64 * d];
+        const double2 w = wsp[64 * d];
+        const cd e = {v[d].x + zm.x, v[d].y - zm.y};                  // Z + conj Zm
+        const cd o = {v[d].y + zm.y, zm.x - v[d].x};                  // -j (Z - conj Zm)
+        const cd p = cd_mul(o, cd{w.x, w.y});
+        f64x2 lo = {0.5 * (e.x + p.x), 0.5 * (e.y + p.y)}, hi = {0.5 * (e.x - p.x), 0.5 * (e.y - p.y)};
+        __builtin_nontemporal_store(lo, dst + 64 * d);
+        __builtin_nontemporal_store(hi, dst + 64 * d + 512);
+    }
+}
+
+int launch_stft1024_f64(hipStream_t stream, const short *pcm, long n_frames, long hop, const double *table,
+                        const double2 *tw512, double2 *out)
+{
+    if (n_frames <= 0) return 0;
+    const long grid = (n_frames + 7) / 8 * 8;
+    hipLaunchKernelGGL(stft1024_f64_kernel, dim3((unsigned)grid), dim3(64), 0, stream, pcm, n_frames, hop, table, tw512, out);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// host side of the table: the reference's window (SS:226) and the split twiddles
+void fill_stft1024_f64_table(double *t)
+{
+    const double PI = 3.141592;                                      // SS:52
+    for (int i = 0; i < 1024; i++) t[i] = 0.54 - 0.46 * cos(2 * PI * i / (1024 - 1));
+    const double two_pi = 6.283185307179586476925286766559;
+    for (int m = 0; m < 512; m++) {
+        const double a = -two_pi * (double)m / 1024.0;
+        t[1024 + 2 * m] = cos(a);
+        t[1024 + 2 * m + 1] = sin(a);
+    }
+}
+
 int launch_fft_process_f64(hipStream_t stream, const double2 *in, double2 *out, int n_fft, int log2n, long batch,
                            int forward, const double2 *tw)
 {

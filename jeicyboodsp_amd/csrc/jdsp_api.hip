@@ -55,6 +55,8 @@ using jdsp::fail;
 
 extern "C" {
 
+static int ensure_c2c_tw(jdsp_ctx *ctx, int n_fft, int lg);
+
 int jdsp_abi_version(void) { return JDSP_ABI_VERSION; }
 
 int jdsp_create(int device, jdsp_ctx **out)
@@ -97,6 +99,7 @@ int jdsp_destroy(jdsp_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->stft1024_table) (void)hipFree(ctx->stft1024_table);
+    if (ctx->stft_f64_table) (void)hipFree(ctx->stft_f64_table);
     for (auto &p : ctx->c2c_tw)
         if (p) (void)hipFree(p);
     if (ctx->vad_w_hi) (void)hipFree(ctx->vad_w_hi);
@@ -281,11 +284,9 @@ int jdsp_fft_process_f64_dev(jdsp_ctx *ctx, const double *in_dev, double *out_de
     if (batch < 0 || (batch > 0 && (!in_dev || !out_dev))) return fail(ctx, JDSP_EINVAL, "jdsp_fft_process_f64: bad buffer");
     if (batch == 0) return JDSP_OK;
     JDSP_HIP(ctx, hipSetDevice(ctx->device));
-    if (!ctx->c2c_tw[lg]) {
-        std::vector<double2> host((size_t)n_fft / 2 + 1);
-        jdsp::fill_c2c_twiddles(host.data(), n_fft);
-        JDSP_HIP(ctx, hipMalloc((void **)&ctx->c2c_tw[lg], sizeof(double2) * host.size()));
-        JDSP_HIP(ctx, hipMemcpy(ctx->c2c_tw[lg], host.data(), sizeof(double2) * host.size(), hipMemcpyHostToDevice));
+    {
+        const int rc_tw = ensure_c2c_tw(ctx, n_fft, lg);
+        if (rc_tw) return rc_tw;
     }
     if (jdsp::launch_fft_process_f64(ctx->stream, (const double2 *)in_dev, (double2 *)out_dev, n_fft, lg, batch, forward,
                                      ctx->c2c_tw[lg]))
@@ -537,6 +538,71 @@ static int stft_pipelined(jdsp_ctx *ctx, const int16_t *pcm_host, long n_frames,
     }
     hipError_t e1 = hipStreamSynchronize(ctx->pipe_in), e2 = hipStreamSynchronize(comp), e3 = hipStreamSynchronize(ctx->pipe_out);
     if (!rc && (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess)) rc = fail(ctx, JDSP_EHIP, "stft pipeline: sync", e1 != hipSuccess ? e1 : (e2 != hipSuccess ? e2 : e3));
+    return rc;
+}
+
+static int ensure_c2c_tw(jdsp_ctx *ctx, int n_fft, int lg)
+{
+    if (ctx->c2c_tw[lg]) return JDSP_OK;
+    std::vector<double2> host((size_t)n_fft / 2 + 1);
+    jdsp::fill_c2c_twiddles(host.data(), n_fft);
+    JDSP_HIP(ctx, hipMalloc((void **)&ctx->c2c_tw[lg], sizeof(double2) * host.size()));
+    JDSP_HIP(ctx, hipMemcpy(ctx->c2c_tw[lg], host.data(), sizeof(double2) * host.size(), hipMemcpyHostToDevice));
+    return JDSP_OK;
+}
+
+int jdsp_stft_i16_f64_dev(jdsp_ctx *ctx, const int16_t *pcm_dev, long n_frames, int n_fft, int hop, double *spec_dev)
+{
+    if (!ctx) return JDSP_EINVAL;
+    if (n_fft != 1024) return fail(ctx, JDSP_EINVAL, "jdsp_stft_i16_f64_dev: n_fft must be 1024");
+    if (hop < 1) return fail(ctx, JDSP_EINVAL, "jdsp_stft_i16_f64_dev: hop must be >= 1");
+    if (n_frames < 0 || (n_frames > 0 && (!pcm_dev || !spec_dev))) return fail(ctx, JDSP_EINVAL, "jdsp_stft_i16_f64_dev: bad buffer");
+    if (n_frames == 0) return JDSP_OK;
+    if ((uintptr_t)pcm_dev & 1u) return fail(ctx, JDSP_EINVAL, "jdsp_stft_i16_f64_dev: pcm must be 2-byte aligned");
+    if ((uintptr_t)spec_dev & 15u) return fail(ctx, JDSP_EINVAL, "jdsp_stft_i16_f64_dev: spec must be 16-byte aligned");
+    JDSP_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = ensure_c2c_tw(ctx, 512, 9);
+    if (rc) return rc;
+    if (!ctx->stft_f64_table) {
+        std::vector<double> host(1024 + 2 * 512);
+        jdsp::fill_stft1024_f64_table(host.data());
+        JDSP_HIP(ctx, hipMalloc((void **)&ctx->stft_f64_table, sizeof(double) * host.size()));
+        JDSP_HIP(ctx, hipMemcpy(ctx->stft_f64_table, host.data(), sizeof(double) * host.size(), hipMemcpyHostToDevice));
+    }
+    if (jdsp::launch_stft1024_f64(ctx->stream, pcm_dev, n_frames, hop, ctx->stft_f64_table, ctx->c2c_tw[9], (double2 *)spec_dev))
+        return fail(ctx, JDSP_EHIP, "stft f64 launch", hipGetLastError());
+    return JDSP_OK;
+}
+
+int jdsp_stft_i16_f64(jdsp_ctx *ctx, const int16_t *pcm_host, long n_samples, int n_fft, int hop, double *spec_host,
+                      long *n_frames_out)
+{
+    if (!ctx) return JDSP_EINVAL;
+    if (n_fft != 1024 || hop < 1) return fail(ctx, JDSP_EINVAL, "jdsp_stft_i16_f64: unsupported n_fft/hop");
+    const long n_frames = n_samples >= n_fft ? (n_samples - n_fft) / hop + 1 : 0;
+    if (n_frames_out) *n_frames_out = n_frames;
+    if (n_frames == 0) return JDSP_OK;
+    if (!pcm_host || !spec_host) return fail(ctx, JDSP_EINVAL, "jdsp_stft_i16_f64: NULL buffer");
+    JDSP_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t in_bytes = sizeof(int16_t) * (size_t)((n_frames - 1) * hop + n_fft);
+    const size_t out_bytes = 2 * sizeof(double) * (size_t)n_frames * (size_t)n_fft;
+    int16_t *d_in = nullptr;
+    double *d_out = nullptr;
+    JDSP_HIP(ctx, hipMalloc((void **)&d_in, in_bytes));
+    hipError_t e = hipMalloc((void **)&d_out, out_bytes);
+    if (e != hipSuccess) {
+        (void)hipFree(d_in);
+        return fail(ctx, e == hipErrorOutOfMemory ? JDSP_ENOMEM : JDSP_EHIP, "jdsp_stft_i16_f64: hipMalloc", e);
+    }
+    int rc = JDSP_OK;
+    if ((e = hipMemcpyAsync(d_in, pcm_host, in_bytes, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess)
+        rc = fail(ctx, JDSP_EHIP, "jdsp_stft_i16_f64: H2D", e);
+    if (!rc) rc = jdsp_stft_i16_f64_dev(ctx, d_in, n_frames, n_fft, hop, d_out);
+    if (!rc && (e = hipMemcpyAsync(spec_host, d_out, out_bytes, hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess)
+        rc = fail(ctx, JDSP_EHIP, "jdsp_stft_i16_f64: D2H", e);
+    if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess && !rc) rc = fail(ctx, JDSP_EHIP, "jdsp_stft_i16_f64: sync", e);
+    (void)hipFree(d_in);
+    (void)hipFree(d_out);
     return rc;
 }
 

@@ -32,6 +32,7 @@ struct jdsp_ctx {
     float2 *stft1024_table = nullptr;
     float2 *win512 = nullptr;          // halved Hamming-512 pairs
     double2 *c2c_tw[16] = {nullptr};   // by log2(n_fft)
+    double *stft_f64_table = nullptr;  // FP64 STFT: window + split twiddles (fft_c2c_kernels.hip)
     float2 *conv_tw4096 = nullptr, *conv_tw8192 = nullptr;
     double *vad_w_hi = nullptr;        // second half of the FP64 Hamming window
     // pinned-host pipeline of jdsp_stft_i16: copy-in / compute / copy-out on three streams
@@ -124,6 +125,9 @@ int launch_bitrev_table(hipStream_t stream, short *table_dev, int n_fft, int bit
 int launch_fft_process_f64(hipStream_t stream, const double2 *in, double2 *out, int n_fft, int log2n, long batch,
                            int forward, const double2 *tw);
 void fill_c2c_twiddles(double2 *t, int n_fft);
+int launch_stft1024_f64(hipStream_t stream, const short *pcm, long n_frames, long hop, const double *table,
+                        const double2 *tw512, double2 *out);
+void fill_stft1024_f64_table(double *t);          // [1024 window doubles][512 double2 split twiddles]
 int launch_dft_direct_f64(hipStream_t stream, int kind, const void *in, double2 *inout, int n, long batch);
 
 

@@ -208,6 +208,32 @@ class Engine:
         assert nf.value == want
         return res
 
+    def stft_f64(self, pcm, n_frames=None, hop=512, out=None):
+        """The 1024-point analysis in FP64 (jdsp_stft_i16_f64*): complex128 [n_frames, 1024]."""
+        n_fft = 1024
+        if _is_torch(pcm):
+            import torch
+            assert pcm.is_cuda and pcm.dtype == torch.int16 and pcm.is_contiguous()
+            total = pcm.numel()
+            if n_frames is None:
+                n_frames = (total - n_fft) // hop + 1 if total >= n_fft else 0
+            assert n_frames == 0 or hop * (n_frames - 1) + n_fft <= total, "pcm too short"
+            if out is None:
+                out = torch.empty((n_frames, n_fft), dtype=torch.complex128, device=pcm.device)
+            assert out.is_contiguous() and out.dtype == torch.complex128 and out.numel() >= n_frames * n_fft
+            self._use_torch_stream()
+            self._ck(L.jdsp_stft_i16_f64_dev(self._h, C.c_void_p(pcm.data_ptr()), n_frames, n_fft, hop,
+                                             C.c_void_p(out.data_ptr())))
+            return out
+        pcm = np.ascontiguousarray(pcm, np.int16)
+        nf = C.c_long()
+        want = (pcm.size - n_fft) // hop + 1 if pcm.size >= n_fft else 0
+        res = np.empty((max(want, 0), n_fft), np.complex128)
+        self._ck(L.jdsp_stft_i16_f64(self._h, pcm.ctypes.data_as(C.c_void_p), pcm.size, n_fft, hop,
+                                     res.ctypes.data_as(C.c_void_p), C.byref(nf)))
+        assert nf.value == want
+        return res
+
 
 class Denoiser:
     """One SS/Wiener audio stream (jdsp_denoise): mirrors main()'s loop of

@@ -196,3 +196,20 @@ def test_stft_read_pass_slabs_do_not_change_a_single_bit(eng, oracle):
         assert (np.abs(got - want) / np.abs(want).max(axis=1, keepdims=True)).max() < TOL
     with pytest.raises(Exception):
         eng.set_option("stft.read_pass", 2)
+
+
+def test_full_batch_fp64_stft_agrees_with_the_headline_kernel(eng):
+    """65,536 frames through jdsp_stft_i16_f64_dev (1 GiB of complex128): Hermitian, and the FP32 headline kernel's
+    spectrum within 1e-5 of it frame by frame."""
+    import torch
+    g = torch.Generator(device="cpu").manual_seed(5)
+    n_frames = 65536
+    pcm = (torch.randn(512 * (n_frames + 1), generator=g) * 5000).clamp(-32768, 32767).round().to(torch.int16).cuda()
+    f64 = eng.stft_f64(pcm, n_frames, 512)
+    f32 = eng.stft(pcm, n_frames, 1024, 512)
+    torch.cuda.synchronize()
+    peak = f64.abs().amax(dim=1, keepdim=True)
+    assert float(((f32.to(torch.complex128) - f64).abs() / peak).max()) < 1e-5
+    herm = (f64[:, 1:512] - f64[:, 513:].flip(1).conj()).abs() / peak
+    assert float(herm.max()) < 1e-12
+    assert float(f64[:, 0].imag.abs().max()) == 0.0 or float((f64[:, 0].imag.abs() / peak[:, 0]).max()) < 1e-12

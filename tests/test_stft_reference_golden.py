@@ -79,3 +79,36 @@ def test_gpu_stft_matches_reference_fftprocess_golden(golden_dir, n):
         assert np.array_equal(got, host)                                          # same kernel either way
     finally:
         eng.close()
+
+
+@pytest.mark.gpu
+def test_gpu_fp64_stft_matches_reference_fftprocess_golden(oracle, golden_dir):
+    """The analysis in the reference's own precision (jdsp_stft_i16_f64*): against the reference's FFTProcess on the
+    same windowed frames to 1e-9 of the frame peak (observed ~1e-11: FFTProcess's truncated PI, FFT:15), against the
+    FP64 CPU restatement on a longer seeded stream to 1e-12, and the FP32 headline kernel against it to 1e-5."""
+    import torch
+    import jeicyboodsp_amd
+    eng = jeicyboodsp_amd.Engine(0)
+    try:
+        pcm, hop, want = _golden(golden_dir, 1024)
+        nf = want.shape[0]
+        host = eng.stft_f64(pcm, hop=hop)
+        assert host.shape == (nf, 1024) and host.dtype == np.complex128
+        assert _rel_err(host, want) < 1e-9
+        dev = eng.stft_f64(torch.from_numpy(pcm).cuda(), nf, hop)
+        torch.cuda.synchronize()
+        assert np.array_equal(dev.cpu().numpy(), host)
+        rng = np.random.default_rng(77)
+        for hop2 in (512, 160, 1):
+            n_frames = 300
+            x = np.clip(np.rint(rng.normal(0, 6000, hop2 * (n_frames - 1) + 1024)), -32768, 32767).astype(np.int16)
+            got = eng.stft_f64(x, hop=hop2)
+            ref = oracle.stft(x, n_frames, 1024, hop2)
+            assert _rel_err(got, ref) < 1e-12
+            f32 = eng.stft(x, n_fft=1024, hop=hop2)
+            assert _rel_err(f32.astype(np.complex128), got) < 1e-5
+        with pytest.raises(Exception):
+            eng.stft_f64(torch.zeros(4096, dtype=torch.int16, device="cuda")[1:].contiguous(), 1, 512,
+                         out=torch.empty((1, 1024), dtype=torch.complex128, device="cuda").view(torch.float64)[1:])
+    finally:
+        eng.close()

@@ -115,6 +115,14 @@ def main():
             ms = timed(lambda: eng.stft_half(x, B, out=hs, pitch=pitch), a.iters)
             report(f"stft_half_spectrum_513_bins_pitch{pitch}", ms, B, "frames", 1024 + 4104, 5 * 512 * 9 + 512 * 14,
                    "extra: bins 0..512 only (5,128 algorithmic bytes per frame); the headline keeps all 1024 bins")
+    if on("stft_f64"):
+        x = torch.from_numpy(pcm_of(rng, 512 * (B + 1))).cuda()
+        xr = rot(x)
+        o64 = torch.empty((B, 1024), dtype=torch.complex128, device="cuda")
+        ms = timed(lambda: eng.stft_f64(xr(), B, 512, out=o64), a.iters)
+        report("stft_1024_hop512_fp64", ms, B, "frames", 1024 + 16384, 5 * 512 * 9 + 512 * 14,
+               "the headline analysis in the reference's own precision: FP64 window and transform, complex128 full spectrum "
+               "(17,408 algorithmic bytes per frame); flops are FP64")
     if on("denoise"):
         x = pcm_of(rng, B * 512)
         x[:12 * 512] = pcm_of(rng, 12 * 512, 45.0)          # the estimate latches at block 10
