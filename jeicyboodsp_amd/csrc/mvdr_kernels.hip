@@ -113,6 +113,23 @@ __global__ __launch_bounds__(1024) void mvdr_prefix_kernel(const double *__restr
     __shared__ double part[2][4][1024];
     const int t = threadIdx.x;
     const int n = range ? range[1] - range[0] : plan->n_events;
+    if (n <= 64) {
+        // a handful of events (a loud stream): four threads walk them, in the reference's own order of additions
+        if (t >= 4) return;
+        double acc = r_in ? r_in[t] : 0.0;
+        if (sums_all)
+            for (int q = 0; q < rank; q++) acc += sums_all[q * 4 + t];
+        if (rver) rver[t] = acc;
+        double sum = 0.0;
+        for (int e = 0; e < n; e++) {
+            acc += delta[(size_t)e * 4 + t];
+            sum += delta[(size_t)e * 4 + t];
+            if (rver) rver[(size_t)(e + 1) * 4 + t] = acc;
+        }
+        if (st_out) st_out->corr[t] = acc;
+        if (total) total[t] = sum;
+        return;
+    }
     const int per = (n + 1023) >> 10;
     const int e0 = t * per < n ? t * per : n, e1 = e0 + per < n ? e0 + per : n;
     double s[4] = {0.0, 0.0, 0.0, 0.0};
