@@ -73,6 +73,8 @@ struct DenoiseShard {
 };
 
 // BeamForming_MVDR_ver1.cpp's state between calls (device memory)
+constexpr int kMvnChunks = 32;             // chunks the n-microphone covariance update cuts a call's events into
+
 struct MvdrState {
     int run_len;          // main(): iNumOfIteration             MVDR:59,99,108
     int pad[3];
@@ -214,11 +216,11 @@ int launch_mvdr_shard_finish(hipStream_t s, const short *left_ext, const short *
 int launch_mvdrn(hipStream_t s, const short *pcm, long chan_stride, int n_mics, long n_blocks, long calls_before,
                  const short *prev_in, short *prev_out, const int *events, const DenoisePlan *plan, const int *ver_base,
                  const unsigned long long *snap_mask, float2 *spec, const double2 *cov_in, double2 *cov_out,
-                 const double2 *steer, double loading, float2 *weights, const float2 *table, short *out, float *precast);
+                 const double2 *steer, double loading, float2 *weights, const float2 *table, short *out, float *precast, double2 *chunk_ws);
 int launch_mvdrn512(hipStream_t s, const short *pcm, long chan_stride, int n_mics, long n_blocks, long calls_before,
                     const short *prev_in, short *prev_out, const int *events, const DenoisePlan *plan, const int *ver_base,
                     const unsigned long long *snap_mask, float2 *spec, const double2 *cov_in, double2 *cov_out,
-                    const double2 *steer, double loading, float2 *weights, const float2 *table, short *out, float *precast);
+                    const double2 *steer, double loading, float2 *weights, const float2 *table, short *out, float *precast, double2 *chunk_ws);
 // pitch_kernels.hip
 int launch_pitch(hipStream_t s, const short *pcm, long n_blocks, const short *prev_block, const float2 *table, int *arg,
                  float *rmax, float *autocorr);
@@ -357,4 +359,5 @@ struct jdsp_mvdrn {
     int *events = nullptr, *ev_n = nullptr, *ver_base = nullptr;
     unsigned long long *snap_mask = nullptr;
     float2 *spec = nullptr, *weights = nullptr;
+    double2 *chunk_ws = nullptr;              // [2][kMvnChunks][n_bins][64]: per-chunk covariance sums and entering matrices
 };

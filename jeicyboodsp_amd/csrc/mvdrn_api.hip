@@ -58,6 +58,7 @@ int jdsp_mvdrn_create_cfg(jdsp_ctx *ctx, int n_mics, const double *delays_s, dou
         if (e == hipSuccess) e = hipMalloc((void **)&h->run_len[i], sizeof(int));
     }
     if (e == hipSuccess) e = hipMalloc((void **)&h->plan, sizeof(jdsp::DenoisePlan));
+    if (e == hipSuccess) e = hipMalloc((void **)&h->chunk_ws, sizeof(double2) * 2 * jdsp::kMvnChunks * (size_t)513 * 64);
     if (e == hipSuccess) e = hipMalloc((void **)&h->steer, sizeof(double2) * steer.size());
     if (e == hipSuccess) e = hipMalloc((void **)&h->w_vad, sizeof(w));
     if (e == hipSuccess) e = hipMemcpy(h->steer, steer.data(), sizeof(double2) * steer.size(), hipMemcpyHostToDevice);
@@ -87,6 +88,7 @@ int jdsp_mvdrn_destroy(jdsp_mvdrn *h)
         if (h->run_len[i]) (void)hipFree(h->run_len[i]);
     }
     if (h->plan) (void)hipFree(h->plan);
+    if (h->chunk_ws) (void)hipFree(h->chunk_ws);
     if (h->steer) (void)hipFree(h->steer);
     if (h->w_vad) (void)hipFree(h->w_vad);
     delete h;
@@ -160,7 +162,7 @@ int jdsp_mvdrn_process_dev(jdsp_mvdrn *h, const int16_t *pcm_dev, long chan_stri
                                   h->events, h->ev_n, h->plan) ||
             jdsp::launch_mvdrn512(s, pcm_dev, chan_stride, h->n_mics, n_blocks, h->calls, h->prev[in], h->prev[ou], h->events,
                                   h->plan, h->ver_base, h->snap_mask, h->spec, h->cov[in], h->cov[ou], h->steer, h->loading,
-                                  h->weights, ctx->stft1024_table, out_dev, precast_dev))
+                                  h->weights, ctx->stft1024_table, out_dev, precast_dev, h->chunk_ws))
             return fail(ctx, JDSP_EHIP, "mvdrn512 launch", hipGetLastError());
         h->cur ^= 1;
         h->calls += n_blocks;
@@ -171,7 +173,7 @@ int jdsp_mvdrn_process_dev(jdsp_mvdrn *h, const int16_t *pcm_dev, long chan_stri
                               h->ev_n, h->plan) ||
         jdsp::launch_mvdrn(s, pcm_dev, chan_stride, h->n_mics, n_blocks, h->calls, h->prev[in], h->prev[ou], h->events,
                            h->plan, h->ver_base, h->snap_mask, h->spec, h->cov[in], h->cov[ou], h->steer, h->loading,
-                           h->weights, ctx->stft1024_table, out_dev, precast_dev))
+                           h->weights, ctx->stft1024_table, out_dev, precast_dev, h->chunk_ws))
         return fail(ctx, JDSP_EHIP, "mvdrn launch", hipGetLastError());
     h->cur ^= 1;
     h->calls += n_blocks;
