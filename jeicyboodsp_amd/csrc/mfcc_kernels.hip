@@ -251,6 +251,9 @@ __device__ __forceinline__ double sum_xor32_f64(double a)
     return __hiloint2double(h[0], l[0]) + __hiloint2double(h[1], l[1]);
 }
 
+#ifndef JDSP_MFCC_X2_PAIRS
+#define JDSP_MFCC_X2_PAIRS 1
+#endif
 __global__ __launch_bounds__(64) void mfcc_x2_kernel(const short *__restrict__ pcm, const long long *__restrict__ starts,
                                                      long n_frames, MfccDev p, const float2 *__restrict__ table,
                                                      double *__restrict__ feats)
@@ -280,6 +283,48 @@ __global__ __launch_bounds__(64) void mfcc_x2_kernel(const short *__restrict__ p
     for (int t = 0; t < 16; t++) { sw[t] = p.seg_w[t * 64 + lane]; cw[t] = p.seg_c[t * 64 + lane]; }
 
     wave_fft512_x2<false>(va, vb, lds[0], lds[1], lane, tw);
+#if JDSP_MFCC_X2_PAIRS
+    // |X[m]| and |X[512 - m]| (= |X[m + 512]|) for m = lane + 64 d, d < 5 -- bins 0..319 and 193..511 -- from the
+    // pair-owned split (frame_io.h): five mirror operands per frame through LDS instead of a natural-order image and
+    // two reads of it (11 KB instead of 24 KB per pair of frames through the LDS pipe, which bounds this kernel)
+    float *mag_a = reinterpret_cast<float *>(lds[0]), *mag_b = reinterpret_cast<float *>(lds[1]);
+    {
+        PairTwiddles pw;
+        load_pair_twiddles(pw, table, lane);
+        float2 za[5], zb[5];
+        wave_lds_fence();
+#pragma unroll
+        for (int d = 3; d < 8; d++) { lds[0][lane + 64 * d] = va[d]; lds[1][lane + 64 * d] = vb[d]; }
+        if (lane == 0) { lds[0][512] = va[0]; lds[1][512] = vb[0]; }
+        logmel[0][lane] = 0.f;
+        logmel[1][lane] = 0.f;
+        wave_lds_fence();
+#pragma unroll
+        for (int d = 0; d < 5; d++) { za[d] = lds[0][512 - lane - 64 * d]; zb[d] = lds[1][512 - lane - 64 * d]; }
+        wave_lds_fence();
+#pragma unroll
+        for (int d = 0; d < 5; d++) {
+            const int m = lane + 64 * d, mm = 512 - m;               // mm = 512 (m = 0): X[512], not a mel bin
+            const bool pick = p.bin_stride == 1 || !(m & 1);         // 512-point bins = even 1024-point bins
+            const int hm = p.bin_stride == 1 ? m : m >> 1, hmm = p.bin_stride == 1 ? mm : mm >> 1;
+            const int qm = hm + (hm >> 4), qmm = hmm + (hmm >> 4);
+            {
+                const float2 e = cadd_conj(va[d], za[d]), o = csub_conj_mj(va[d], za[d]);
+                const float2 t = cmul(pw.w[d], o);
+                const float2 lo = cadd(e, t), hi = csub(e, t);
+                if (pick) mag_a[qm] = __builtin_amdgcn_sqrtf(lo.x * lo.x + lo.y * lo.y);
+                if (pick && mm < 512) mag_a[qmm] = __builtin_amdgcn_sqrtf(hi.x * hi.x + hi.y * hi.y);
+            }
+            {
+                const float2 e = cadd_conj(vb[d], zb[d]), o = csub_conj_mj(vb[d], zb[d]);
+                const float2 t = cmul(pw.w[d], o);
+                const float2 lo = cadd(e, t), hi = csub(e, t);
+                if (pick) mag_b[qm] = __builtin_amdgcn_sqrtf(lo.x * lo.x + lo.y * lo.y);
+                if (pick && mm < 512) mag_b[qmm] = __builtin_amdgcn_sqrtf(hi.x * hi.x + hi.y * hi.y);
+            }
+        }
+    }
+#else
     store_natural_image(lds[0], lane, va);
     store_natural_image(lds[1], lane, vb);
     logmel[0][lane] = 0.f;
@@ -306,6 +351,7 @@ __global__ __launch_bounds__(64) void mfcc_x2_kernel(const short *__restrict__ p
             mag_b[q] = amp_b[j].x;
         }
     }
+#endif
     wave_lds_fence();
     // mel filterbank (:157-168), one channel index per lane: bin i of index k adds f_i m_i to channel k - 1 and
     // (1 - f_i) m_i to channel k, so a lane whose bins all share k sums both in registers and issues exactly two
