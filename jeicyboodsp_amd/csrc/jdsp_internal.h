@@ -97,6 +97,10 @@ struct MfccDev {
     const float *seg_w;
     const float *seg_c;          // 1 - seg_w inside a piece, 0 past its last bin
     int seg_ok;
+    // per channel ch: lanes [x, x + y) hold pieces with index ch (their `hi` parts), lanes [z, z + w) pieces with index
+    // ch + 1 (their `lo` parts); chan_ok = no channel needs more than four of either
+    const int4 *chan_src;
+    int chan_ok;
     const double *dct;           // [n_chan][32]: sqrt(2/C) cos(PI i (k-0.5)/C)
     const double *lifter_w;      // [32]: 1 + L/2 sin(PI i / L)
 };

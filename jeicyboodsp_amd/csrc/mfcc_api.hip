@@ -77,6 +77,20 @@ int jdsp_mfcc_create(jdsp_ctx *ctx, const jdsp_mfcc_cfg *cfg, jdsp_mfcc **out)
         }
         i = e;
     }
+    // ---- per channel: which lanes' pieces feed it (mel_channel_sums) ----
+    std::vector<int> chan_src(64 * 4, 0);
+    bool chan_ok = seg_ok;
+    for (int ch = 0; ch < C && chan_ok; ch++) {
+        int h0 = -1, hc = 0, l0 = -1, lc = 0;
+        for (int L = 0; L < seg_lanes; L++) {
+            const int z = seg[4 * L + 2];
+            if (z == ch) { if (h0 < 0) h0 = L; hc++; }
+            if (z == ch + 1) { if (l0 < 0) l0 = L; lc++; }
+        }
+        if (hc > 4 || lc > 4) chan_ok = false;
+        chan_src[4 * ch + 0] = h0 < 0 ? 0 : h0; chan_src[4 * ch + 1] = hc;
+        chan_src[4 * ch + 2] = l0 < 0 ? 0 : l0; chan_src[4 * ch + 3] = lc;
+    }
     // ---- DCT (:178-182) and lifter (:189) constants ----
     std::vector<double> dct((size_t)C * 32, 0.0), lift(32, 0.0);
     for (int i = 1; i <= c.n_cep; i++) {
@@ -94,7 +108,8 @@ int jdsp_mfcc_create(jdsp_ctx *ctx, const jdsp_mfcc_cfg *cfg, jdsp_mfcc **out)
     const size_t o_win = 0, o_fb = o_win + sizeof(float2) * 512, o_k = o_fb + 512 * sizeof(float),
                  o_dct = o_k + 512 * sizeof(int), o_lift = o_dct + dct.size() * sizeof(double),
                  o_seg = o_lift + 32 * sizeof(double), o_segw = o_seg + seg.size() * sizeof(int),
-                 o_segc = o_segw + seg_w.size() * sizeof(float), total = o_segc + seg_c.size() * sizeof(float);
+                 o_segc = o_segw + seg_w.size() * sizeof(float), o_chan = o_segc + seg_c.size() * sizeof(float),
+                 total = o_chan + chan_src.size() * sizeof(int);
     std::vector<char> host(total, 0);
     memcpy(&host[o_win], window.data(), sizeof(float2) * 512);
     memcpy(&host[o_fb], mel_fb.data(), 512 * sizeof(float));
@@ -104,6 +119,7 @@ int jdsp_mfcc_create(jdsp_ctx *ctx, const jdsp_mfcc_cfg *cfg, jdsp_mfcc **out)
     memcpy(&host[o_seg], seg.data(), seg.size() * sizeof(int));
     memcpy(&host[o_segw], seg_w.data(), seg_w.size() * sizeof(float));
     memcpy(&host[o_segc], seg_c.data(), seg_c.size() * sizeof(float));
+    memcpy(&host[o_chan], chan_src.data(), chan_src.size() * sizeof(int));
     hipError_t e = hipMalloc(&h->blob, total);
     if (e == hipSuccess) e = hipMemcpy(h->blob, host.data(), total, hipMemcpyHostToDevice);
     if (e != hipSuccess) {
@@ -122,6 +138,8 @@ int jdsp_mfcc_create(jdsp_ctx *ctx, const jdsp_mfcc_cfg *cfg, jdsp_mfcc **out)
     h->dev.seg_w = (const float *)(b + o_segw);
     h->dev.seg_c = (const float *)(b + o_segc);
     h->dev.seg_ok = seg_ok ? 1 : 0;
+    h->dev.chan_src = (const int4 *)(b + o_chan);
+    h->dev.chan_ok = chan_ok ? 1 : 0;
     h->dev.dct = (const double *)(b + o_dct);
     h->dev.lifter_w = (const double *)(b + o_lift);
     *out = h;

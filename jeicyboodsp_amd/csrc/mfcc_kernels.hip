@@ -251,8 +251,41 @@ __device__ __forceinline__ double sum_xor32_f64(double a)
     return __hiloint2double(h[0], l[0]) + __hiloint2double(h[1], l[1]);
 }
 
+// Channel sums from the lanes' pieces.  Lane L holds (lo, hi) = its piece's contributions to the channels seg[L].z - 1 and
+// seg[L].z; the pieces of one index are consecutive lanes, so channel ch is the sum of `hi` over lanes [src.x, +src.y)
+// and of `lo` over lanes [src.z, +src.w) (chan_src[ch], at most four each when chan_ok).  Two plain stores per lane
+// and frame and a few reads on the channel lanes instead of two LDS atomics per lane and frame: the atomics were 10 us
+// of mfcc_x2_kernel's 95 (profiles/r02_mfcc512_run.txt), and their order -- hence the last bit of the sum -- was not
+// reproducible.  pieces: 2 x 2 x 64 floats of LDS.
+__device__ __forceinline__ void mel_channel_sums(float (*pieces)[2][64], float (*logmel)[64], const MfccDev &p, int lane,
+                                                 float lo_a, float hi_a, float lo_b, float hi_b)
+{
+    pieces[0][0][lane] = lo_a; pieces[0][1][lane] = hi_a;
+    pieces[1][0][lane] = lo_b; pieces[1][1][lane] = hi_b;
+    wave_lds_fence();
+    if (lane < p.n_chan) {
+        const int4 src = p.chan_src[lane];
+        float sa = 0.f, sb = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const int ih = src.x + (t < src.y ? t : 0), il = src.z + (t < src.w ? t : 0);
+            const float ha = pieces[0][1][ih], hb = pieces[1][1][ih], la = pieces[0][0][il], lb = pieces[1][0][il];
+            sa += (t < src.y ? ha : 0.f) + (t < src.w ? la : 0.f);
+            sb += (t < src.y ? hb : 0.f) + (t < src.w ? lb : 0.f);
+        }
+        // :171.  Hardware log2 times ln 2 (1 ulp of the FP32 logarithm; logf() is ~25 instructions of range fix-up
+        // per value for the last half ulp, of which nothing survives the 1e-5 bar); ln 0 = -inf as in the reference
+        logmel[0][lane] = __logf(sa);
+        logmel[1][lane] = __logf(sb);
+    }
+    wave_lds_fence();
+}
+
 #ifndef JDSP_MFCC_X2_PAIRS
 #define JDSP_MFCC_X2_PAIRS 1
+#endif
+#ifndef JDSP_MFCC_ABLATE
+#define JDSP_MFCC_ABLATE 0        // timing-only ablations of mfcc_x2_kernel's tail (tools/build_variant.sh): wrong results
 #endif
 __global__ __launch_bounds__(64) void mfcc_x2_kernel(const short *__restrict__ pcm, const long long *__restrict__ starts,
                                                      long n_frames, MfccDev p, const float2 *__restrict__ table,
@@ -260,6 +293,7 @@ __global__ __launch_bounds__(64) void mfcc_x2_kernel(const short *__restrict__ p
 {
     __shared__ __attribute__((aligned(16))) float2 lds[2][kWaveLdsComplex];
     __shared__ float logmel[2][64];
+    __shared__ float pieces[2][2][64];
     const int lane = threadIdx.x;
     const long per_xcd = (gridDim.x + 7) >> 3;
     const long fa = ((long)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3)) * 2;
@@ -364,27 +398,34 @@ __global__ __launch_bounds__(64) void mfcc_x2_kernel(const short *__restrict__ p
         for (int t = 0; t < 16; t++) {                               // all thirty-two reads in flight together
             const int bin = min(sg.x + t, 511);                      // past the piece: any finite value, its weights are 0
             const int q = bin + (bin >> 4);
+#if JDSP_MFCC_ABLATE & 1                                             /* timing-only: no filterbank reads */
+            ma[t] = (float)q; mb[t] = (float)(q + 1);
+#else
             ma[t] = mag_a[q];
             mb[t] = mag_b[q];
+#endif
         }
 #pragma unroll
         for (int t = 0; t < 16; t++) {
             lo_a = fmaf(sw[t], ma[t], lo_a); hi_a = fmaf(cw[t], ma[t], hi_a);   // :164 / :161,:165-166
             lo_b = fmaf(sw[t], mb[t], lo_b); hi_b = fmaf(cw[t], mb[t], hi_b);
         }
-        if (sg.y > 0) {
-            if (sg.z >= 1) { atomicAdd(&logmel[0][sg.z - 1], lo_a); atomicAdd(&logmel[1][sg.z - 1], lo_b); }
-            if (sg.z < p.n_chan) { atomicAdd(&logmel[0][sg.z], hi_a); atomicAdd(&logmel[1][sg.z], hi_b); }
+        if (p.chan_ok) {
+            if (sg.y <= 0) { lo_a = hi_a = lo_b = hi_b = 0.f; }
+            mel_channel_sums(pieces, logmel, p, lane, lo_a, hi_a, lo_b, hi_b);
+        } else {
+            if (sg.y > 0) {
+                if (sg.z >= 1) { atomicAdd(&logmel[0][sg.z - 1], lo_a); atomicAdd(&logmel[1][sg.z - 1], lo_b); }
+                if (sg.z < p.n_chan) { atomicAdd(&logmel[0][sg.z], hi_a); atomicAdd(&logmel[1][sg.z], hi_b); }
+            }
+            wave_lds_fence();
+            if (lane < p.n_chan) {
+                logmel[0][lane] = __logf(logmel[0][lane]);               // :171, as in mel_channel_sums
+                logmel[1][lane] = __logf(logmel[1][lane]);
+            }
+            wave_lds_fence();
         }
     }
-    wave_lds_fence();
-    if (lane < p.n_chan) {
-        // :171.  Hardware log2 times ln 2 (1 ulp of the FP32 logarithm; logf() is ~25 instructions of range fix-up
-        // per value for the last half ulp, of which nothing survives the 1e-5 bar); ln 0 = -inf as in the reference
-        logmel[0][lane] = __logf(logmel[0][lane]);
-        logmel[1][lane] = __logf(logmel[1][lane]);
-    }
-    wave_lds_fence();
     // DCT-II (:178-182) and lifter (:189), both frames off one pass over the table
     {
         const bool wide = p.n_cep > 16;                              // see mfcc_kernel
@@ -425,8 +466,9 @@ __device__ __forceinline__ void load_mel_piece(MelPiece &m, const MfccDev &p, in
 }
 
 // |X| of two frames, bin i at mag[i + (i >> 4)] (see mfcc_x2_kernel) -> feats[fa], feats[fb]
-__device__ __forceinline__ void mfcc_tail_x2(const float *mag_a, const float *mag_b, float (*logmel)[64], const MfccDev &p,
-                                             int lane, const MelPiece &mp, long fa, long fb, bool two, double *__restrict__ feats)
+__device__ __forceinline__ void mfcc_tail_x2(const float *mag_a, const float *mag_b, float (*logmel)[64], float (*pieces)[2][64],
+                                             const MfccDev &p, int lane, const MelPiece &mp, long fa, long fb, bool two,
+                                             double *__restrict__ feats)
 {
     {
         float lo_a = 0.f, hi_a = 0.f, lo_b = 0.f, hi_b = 0.f;
@@ -444,17 +486,22 @@ __device__ __forceinline__ void mfcc_tail_x2(const float *mag_a, const float *ma
             lo_a = fmaf(mp.sw[t], ma[t], lo_a); hi_a = fmaf(mp.cw[t], ma[t], hi_a);   // :164 / :161,:165-166
             lo_b = fmaf(mp.sw[t], mb[t], lo_b); hi_b = fmaf(mp.cw[t], mb[t], hi_b);
         }
-        if (mp.sg.y > 0) {
-            if (mp.sg.z >= 1) { atomicAdd(&logmel[0][mp.sg.z - 1], lo_a); atomicAdd(&logmel[1][mp.sg.z - 1], lo_b); }
-            if (mp.sg.z < p.n_chan) { atomicAdd(&logmel[0][mp.sg.z], hi_a); atomicAdd(&logmel[1][mp.sg.z], hi_b); }
+        if (p.chan_ok) {
+            if (mp.sg.y <= 0) { lo_a = hi_a = lo_b = hi_b = 0.f; }
+            mel_channel_sums(pieces, logmel, p, lane, lo_a, hi_a, lo_b, hi_b);
+        } else {
+            if (mp.sg.y > 0) {
+                if (mp.sg.z >= 1) { atomicAdd(&logmel[0][mp.sg.z - 1], lo_a); atomicAdd(&logmel[1][mp.sg.z - 1], lo_b); }
+                if (mp.sg.z < p.n_chan) { atomicAdd(&logmel[0][mp.sg.z], hi_a); atomicAdd(&logmel[1][mp.sg.z], hi_b); }
+            }
+            wave_lds_fence();
+            if (lane < p.n_chan) {                                   // :171, hardware log2 (see mel_channel_sums)
+                logmel[0][lane] = __logf(logmel[0][lane]);
+                logmel[1][lane] = __logf(logmel[1][lane]);
+            }
+            wave_lds_fence();
         }
     }
-    wave_lds_fence();
-    if (lane < p.n_chan) {                                           // :171, hardware log2 (see mfcc_x2_kernel)
-        logmel[0][lane] = __logf(logmel[0][lane]);
-        logmel[1][lane] = __logf(logmel[1][lane]);
-    }
-    wave_lds_fence();
     const bool wide = p.n_cep > 16;                                  // DCT-II (:178-182) and lifter (:189), see mfcc_kernel
     const int i = wide ? (lane & 31) : (lane & 15), part = wide ? (lane >> 5) : (lane >> 4), step = wide ? 2 : 4;
     double acc_a = 0.0, acc_b = 0.0;
@@ -555,6 +602,7 @@ __global__ __launch_bounds__(64, JDSP_MFCC512_WAVES) void mfcc512_run_kernel(con
 {
     __shared__ __attribute__((aligned(16))) float2 lds[kWaveLdsComplex];
     __shared__ float logmel[2][64];
+    __shared__ float pieces[2][2][64];
     const int lane = threadIdx.x;
     const long n_pairs = (n_frames + 1) >> 1;
     if ((long)blockIdx.x >= n_pairs) return;
@@ -600,7 +648,7 @@ __global__ __launch_bounds__(64, JDSP_MFCC512_WAVES) void mfcc512_run_kernel(con
         logmel[0][lane] = 0.f;
         logmel[1][lane] = 0.f;
         wave_lds_fence();
-        mfcc_tail_x2(mag_a, mag_b, logmel, p, lane, mp, fa, fb, two, feats);
+        mfcc_tail_x2(mag_a, mag_b, logmel, pieces, p, lane, mp, fa, fb, two, feats);
     }
 }
 
