@@ -291,9 +291,11 @@ __global__ __launch_bounds__(64) void mfcc_x2_kernel(const short *__restrict__ p
                                                      long n_frames, MfccDev p, const float2 *__restrict__ table,
                                                      double *__restrict__ feats)
 {
+    // 9,344 B per wave: the two transform scratches; |X| (544 floats each), the filterbank pieces and the channel
+    // logarithms live in the scratches' second halves (seventeen waves per CU instead of fourteen)
     __shared__ __attribute__((aligned(16))) float2 lds[2][kWaveLdsComplex];
-    __shared__ float logmel[2][64];
-    __shared__ float pieces[2][2][64];
+    float (*logmel)[64] = reinterpret_cast<float (*)[64]>(reinterpret_cast<float *>(lds[0]) + 640);       // [2][64]
+    float (*pieces)[2][64] = reinterpret_cast<float (*)[2][64]>(reinterpret_cast<float *>(lds[1]) + 640); // [2][2][64]
     const int lane = threadIdx.x;
     const long per_xcd = (gridDim.x + 7) >> 3;
     const long fa = ((long)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3)) * 2;
@@ -311,6 +313,8 @@ __global__ __launch_bounds__(64) void mfcc_x2_kernel(const short *__restrict__ p
     // channel sg.z - 1 and cw[t] = 1 - sw[t] towards channel sg.z; both are ZERO past the piece's last bin, so the
     // sixteen steps below need neither a branch nor a select (the branchy form compiled to 94 exec-mask regions
     // with a dependent LDS read and an s_waitcnt in each: the kernel spent 65 % of its wave cycles waiting)
+    const bool wide = p.n_cep > 16;                                  // see mfcc_kernel
+    const int ci = wide ? (lane & 31) : (lane & 15), cpart = wide ? (lane >> 5) : (lane >> 4), cstep = wide ? 2 : 4;
     const int4 sg = p.seg[lane];
     float sw[16], cw[16];
 #pragma unroll
@@ -330,12 +334,12 @@ __global__ __launch_bounds__(64) void mfcc_x2_kernel(const short *__restrict__ p
 #pragma unroll
         for (int d = 3; d < 8; d++) { lds[0][lane + 64 * d] = va[d]; lds[1][lane + 64 * d] = vb[d]; }
         if (lane == 0) { lds[0][512] = va[0]; lds[1][512] = vb[0]; }
-        logmel[0][lane] = 0.f;
-        logmel[1][lane] = 0.f;
         wave_lds_fence();
 #pragma unroll
         for (int d = 0; d < 5; d++) { za[d] = lds[0][512 - lane - 64 * d]; zb[d] = lds[1][512 - lane - 64 * d]; }
         wave_lds_fence();
+        logmel[0][lane] = 0.f;                                       // (their home overlaps the image just read)
+        logmel[1][lane] = 0.f;
 #pragma unroll
         for (int d = 0; d < 5; d++) {
             const int m = lane + 64 * d, mm = 512 - m;               // mm = 512 (m = 0): X[512], not a mel bin
@@ -361,13 +365,13 @@ __global__ __launch_bounds__(64) void mfcc_x2_kernel(const short *__restrict__ p
 #else
     store_natural_image(lds[0], lane, va);
     store_natural_image(lds[1], lane, vb);
-    logmel[0][lane] = 0.f;
-    logmel[1][lane] = 0.f;
     wave_lds_fence();
     float2 amp_a[4], amp_b[4];
     mfcc_magnitudes(lds[0], lane, wsp0, wsp1, amp_a);
     mfcc_magnitudes(lds[1], lane, wsp0, wsp1, amp_b);
     wave_lds_fence();                                                // every lane's split reads are done: overwrite
+    logmel[0][lane] = 0.f;
+    logmel[1][lane] = 0.f;
     float *mag_a = reinterpret_cast<float *>(lds[0]), *mag_b = reinterpret_cast<float *>(lds[1]);
     // |X| is stored PADDED, bin i at i + (i >> 4): the filterbank below reads it one piece per lane, and the pieces
     // of the wide upper channels start 16 bins apart -- unpadded, those lanes' addresses are 16 words apart and fall
@@ -387,6 +391,14 @@ __global__ __launch_bounds__(64) void mfcc_x2_kernel(const short *__restrict__ p
     }
 #endif
     wave_lds_fence();
+    // the DCT coefficients this lane will need (up to ten channels per quarter of the wave: 40 channels), requested
+    // now -- the transforms' registers are free again -- so that they have arrived when the channel logarithms have
+    double dc[10];
+#pragma unroll
+    for (int t = 0; t < 10; t++) {
+        const int k = cpart + cstep * t;
+        dc[t] = (ci < p.n_cep && k < p.n_chan) ? p.dct[k * 32 + ci] : 0.0;
+    }
     // mel filterbank (:157-168), one channel index per lane: bin i of index k adds f_i m_i to channel k - 1 and
     // (1 - f_i) m_i to channel k, so a lane whose bins all share k sums both in registers and issues exactly two
     // LDS atomics.  (Walking 8 consecutive bins per lane and flushing whenever the index changed took ~18
@@ -428,12 +440,20 @@ __global__ __launch_bounds__(64) void mfcc_x2_kernel(const short *__restrict__ p
     }
     // DCT-II (:178-182) and lifter (:189), both frames off one pass over the table
     {
-        const bool wide = p.n_cep > 16;                              // see mfcc_kernel
-        const int i = wide ? (lane & 31) : (lane & 15), part = wide ? (lane >> 5) : (lane >> 4), step = wide ? 2 : 4;
+        const int i = ci, part = cpart, step = cstep;
         double acc_a = 0.0, acc_b = 0.0;
         if (i < p.n_cep) {
+#pragma unroll
+            for (int t = 0; t < 10; t++) {
+                const int k = min(part + step * t, p.n_chan - 1);        // past the last channel: dc[t] is 0 -- but ln can be -inf
+                const float la = logmel[0][k], lb = logmel[1][k];
+                if (part + step * t < p.n_chan) {
+                    acc_a += dc[t] * (double)la;
+                    acc_b += dc[t] * (double)lb;
+                }
+            }
 #pragma unroll 4
-            for (int k = part; k < p.n_chan; k += step) {
+            for (int k = part + 10 * step; k < p.n_chan; k += step) {
                 const double c = p.dct[k * 32 + i];
                 acc_a += c * (double)logmel[0][k];
                 acc_b += c * (double)logmel[1][k];
@@ -502,6 +522,8 @@ __device__ __forceinline__ void mfcc_tail_x2(const float *mag_a, const float *ma
             wave_lds_fence();
         }
     }
+    // (requesting the DCT coefficients ahead of the filterbank, as mfcc_x2_kernel does, costs this kernel 20 registers
+    // it does not have: 73 spills at three waves per SIMD, 168 us)
     const bool wide = p.n_cep > 16;                                  // DCT-II (:178-182) and lifter (:189), see mfcc_kernel
     const int i = wide ? (lane & 31) : (lane & 15), part = wide ? (lane >> 5) : (lane >> 4), step = wide ? 2 : 4;
     double acc_a = 0.0, acc_b = 0.0;
