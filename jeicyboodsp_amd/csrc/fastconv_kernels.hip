@@ -188,11 +188,23 @@ template <int NF, int N0, int BLOCK>
 __global__ __launch_bounds__(64, JDSP_CONV1024_MINWAVES) void fastconv1024_pairs_kernel(ConvStream s, long n_out_blocks, int first_block,
                                                                 const float2 *__restrict__ Hall,
                                                                 const float2 *__restrict__ table, short *__restrict__ out,
-                                                                float *__restrict__ precast, long plane)
+                                                                float *__restrict__ precast, long plane,
+                                                                short *__restrict__ hist_out)
 {
     __shared__ __attribute__((aligned(16))) float2 lds[kWaveLdsComplex];
     const int lane = threadIdx.x;
     if ((long)blockIdx.x >= n_out_blocks) return;
+    if (blockIdx.x == gridDim.x - 1 && hist_out) {
+        // the history the next call starts from (conv_hist_update_kernel's job, without its launch): the last
+        // hist_len samples of [previous history | this call's samples]; hist_out is the other of the handle's two buffers
+        for (int i = lane; i < s.hist_len; i += 64) {
+            const long pos = s.n_samples - s.hist_len + i;
+            short v = 0;
+            if (pos >= 0) v = s.pcm[pos];
+            else if (pos + s.hist_len >= 0) v = s.hist[pos + s.hist_len];
+            hist_out[i] = v;
+        }
+    }
     WaveTwiddles tw;
     load_wave_twiddles(tw, table, lane);
     PairTwiddles pw;
@@ -209,17 +221,28 @@ __global__ __launch_bounds__(64, JDSP_CONV1024_MINWAVES) void fastconv1024_pairs
             Hhi[f][d] = Hall[(size_t)f * 1024 + lane + 64 * d + 512];
         }
 #endif
-    // The launcher hands this kernel only blocks whose whole segment lies inside this call's buffer and past the stream's
-    // silent head (the others go to fastconv1024_kernel): plain loads, no per-sample tests.  A segment starts at a
+    // Plain loads, no per-sample tests (but see the first block below).  A segment starts at a
     // multiple of BLOCK samples, so its sample pairs are 2-byte-aligned dwords (the hardware takes them as they are);
     // the next block's eight are requested before this block's arithmetic starts -- without that the wave spent 61 % of
     // its time in s_waitcnt (profiles/r02_fastconv_pairs.txt).
     typedef unsigned int u32_a2 __attribute__((aligned(2)));
     unsigned int cur[8], nxt[8];
     {
-        const short *src = s.pcm + ((long)(first_block + blockIdx.x + 1) * block - 1024) + 2 * lane;
+        const long start = (long)(first_block + blockIdx.x + 1) * block - 1024;
+        if (start >= 0 && start + s.global0 >= s.valid_from) {
+            const short *src = s.pcm + start + 2 * lane;
 #pragma unroll
-        for (int r = 0; r < 8; r++) nxt[r] = *reinterpret_cast<const u32_a2 *>(src + 128 * r);
+            for (int r = 0; r < 8; r++) nxt[r] = *reinterpret_cast<const u32_a2 *>(src + 128 * r);
+        } else {
+            // the first block or two of a call: the segment reaches into the previous call's history or the stream's
+            // silent head (only a wave's FIRST block can: the ones it goes on to lie a whole grid further)
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const long p0 = start + 2 * lane + 128 * r;
+                const unsigned int a = (unsigned int)(int)conv_sample(s, p0) & 0xffffu, b = (unsigned int)(int)conv_sample(s, p0 + 1);
+                nxt[r] = a | (b << 16);
+            }
+        }
     }
     for (long e = blockIdx.x; e < n_out_blocks; e += gridDim.x) {
 #pragma unroll
@@ -428,27 +451,15 @@ int launch_fastconv(hipStream_t st, int n_fft, const ConvStream &s, long n_out_b
 {
     if (n_out_blocks > 0) {
         if (n_fft == 1024 && JDSP_CONV1024_PAIRS && (n_filters == 1 || n_filters == 2) && n_taps == 256 && block == 769) {
-            // blocks whose segment reaches before this call's buffer or into the stream's silent head (the first one or
-            // two of a call) take the general kernel; the rest the register-resident one, as persistent waves
-            long e_fast = 0;
-            const long lo_pos = s.valid_from - s.global0 > 0 ? s.valid_from - s.global0 : 0;
-            while (e_fast < n_out_blocks && (long)(first_block + e_fast + 1) * block - 1024 < lo_pos) e_fast++;
-            if (e_fast > 0)
-                hipLaunchKernelGGL(fastconv1024_kernel, dim3((unsigned)e_fast), dim3(64), 0, st, s, e_fast, first_block, block,
-                                   n_taps, n_filters, H, table, out, precast, plane);
-            const long n_fast = n_out_blocks - e_fast;
-            if (n_fast > 0) {
-                const unsigned grid = (unsigned)(n_fast < JDSP_CONV1024_GRID ? n_fast : JDSP_CONV1024_GRID);
-                short *out_f = out + e_fast * block;
-                float *pre_f = precast ? precast + e_fast * block : nullptr;
-                const int fb = first_block + (int)e_fast;
-                if (n_filters == 1)
-                    hipLaunchKernelGGL((fastconv1024_pairs_kernel<1, 255, 769>), dim3(grid), dim3(64), 0, st, s, n_fast, fb, H,
-                                       table, out_f, pre_f, plane);
-                else
-                    hipLaunchKernelGGL((fastconv1024_pairs_kernel<2, 255, 769>), dim3(grid), dim3(64), 0, st, s, n_fast, fb, H,
-                                       table, out_f, pre_f, plane);
-            }
+            // persistent waves (a wave's first block may reach into the history / the silent head: handled there)
+            const unsigned grid = (unsigned)(n_out_blocks < JDSP_CONV1024_GRID ? n_out_blocks : JDSP_CONV1024_GRID);
+            if (n_filters == 1)
+                hipLaunchKernelGGL((fastconv1024_pairs_kernel<1, 255, 769>), dim3(grid), dim3(64), 0, st, s, n_out_blocks,
+                                   first_block, H, table, out, precast, plane, s.hist_len > 0 ? hist_out : (short *)nullptr);
+            else
+                hipLaunchKernelGGL((fastconv1024_pairs_kernel<2, 255, 769>), dim3(grid), dim3(64), 0, st, s, n_out_blocks,
+                                   first_block, H, table, out, precast, plane, s.hist_len > 0 ? hist_out : (short *)nullptr);
+            return hipGetLastError() == hipSuccess ? 0 : -1;
         } else if (n_fft == 1024)
             hipLaunchKernelGGL(fastconv1024_kernel, dim3((unsigned)n_out_blocks), dim3(64), 0, st, s, n_out_blocks,
                                first_block, block, n_taps, n_filters, H, table, out, precast, plane);
