@@ -153,3 +153,19 @@ def test_estimate_and_apply_on_their_own_in_any_order(eng, oracle):
     z, zp = m.apply(L[9 * 512:11 * 512], R[9 * 512:11 * 512], np.zeros(4), want_precast=True)
     assert not np.isfinite(zp).any() and not z.any()
     m.close()
+
+
+def test_pause_heavy_stream_uses_the_parallel_prefix(eng, oracle):
+    """Thousands of EstimateSpatialCorrMtx events in one call: the running matrix comes from the 1,024-thread scan
+    (several events per thread), not from the four-thread walk of short event lists."""
+    nb = 3000
+    quiet = tuple((b0, 19) for b0 in range(0, nb - 25, 24))             # ~2,300 quiet blocks
+    L, R = stereo(33, nb, quiet=quiet)
+    o_out, o_pre, o_corr, trace = oracle.mvdr_stream(L, R, 0.0)
+    m = eng.mvdr(0.0)
+    out, pre = m.process(L, R, want_precast=True)
+    check(out, pre, o_out, o_pre)
+    c = m.corr()
+    scale = max(o_corr[0], o_corr[3], 1.0)
+    assert abs(c[0] - o_corr[0]) <= TOL * scale and abs(c[3] - o_corr[3]) <= TOL * scale
+    m.close()

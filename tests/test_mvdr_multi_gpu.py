@@ -152,3 +152,21 @@ def test_mvdrn_cfg_rejects_other_frame_lengths(eng):
     import jeicyboodsp_amd
     with pytest.raises(jeicyboodsp_amd.JdspError):
         eng.mvdr_multi(8, None, 0.0, n_fft=256)
+
+
+@pytest.mark.parametrize("n_fft", [1024, 512])
+def test_many_estimation_frames_per_call(eng, oracle, n_fft):
+    """More events than the covariance update has chunks (32): several events per chunk, chunk sums, the prefix over
+    chunks and the per-chunk walks all in play; the weights of every version are used by some block."""
+    block = n_fft // 2
+    n_blocks = 260
+    quiet = tuple((b0, 17) for b0 in range(2, n_blocks - 20, 23))        # 11 pauses of 17 blocks: ~180 events
+    pcm, _, delays = array_scene(21, 4, n_blocks * block // 512 + 1, quiet=())
+    pcm = pcm[:, :n_blocks * block].copy()
+    for b0, nb in quiet:
+        pcm[:, b0 * block:(b0 + nb) * block] = np.clip(np.rint(np.random.default_rng(b0).normal(0, 25, (4, nb * block))), -200, 200)
+    o_out, o_pre = oracle.mvdrn_stream(pcm, delays, 1e-3, n_fft=n_fft)
+    m = eng.mvdr_multi(4, delays, 1e-3, n_fft=n_fft)
+    out, pre = m.process(pcm, want_precast=True)
+    check(out, pre, o_out, o_pre)
+    m.close()
