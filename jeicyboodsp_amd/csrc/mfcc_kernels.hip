@@ -674,6 +674,66 @@ __global__ __launch_bounds__(64, JDSP_MFCC512_WAVES) void mfcc512_run_kernel(con
     }
 }
 
+// The same pair of frames, ONE pair per wave: nothing is kept between pairs, so the tables are loaded where they are
+// used and die there -- 62 registers instead of 168, eight waves per SIMD instead of three, against ~60 table loads
+// per pair.  This kernel waits on ten LDS round trips per pair and occupancy is what hides them: 53 us per 65,536
+// frames against the persistent kernel's 78, the 10,000-utterance batch 2.7 ms against 4.5 (profiles/r02_mfcc512_run.txt).
+// JDSP_MFCC512_ONE = 0 selects the persistent kernel.
+#ifndef JDSP_MFCC512_ONE
+#define JDSP_MFCC512_ONE 1
+#endif
+__global__ __launch_bounds__(64) void mfcc512_pair_kernel(const short *__restrict__ pcm, const long long *__restrict__ starts,
+                                                          long n_frames, MfccDev p, const float2 *__restrict__ table,
+                                                          double *__restrict__ feats, int *__restrict__ redo)
+{
+    __shared__ __attribute__((aligned(16))) float2 lds[kWaveLdsComplex];
+    float (*logmel)[64] = reinterpret_cast<float (*)[64]>(reinterpret_cast<float *>(lds) + 768);          // [2][64]
+    float (*pieces)[2][64] = reinterpret_cast<float (*)[2][64]>(reinterpret_cast<float *>(lds) + 896);    // [2][2][64]
+    const int lane = threadIdx.x;
+    const long n_pairs = (n_frames + 1) >> 1;
+    const long per_xcd = (gridDim.x + 7) >> 3;
+    const long q = (long)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (q >= n_pairs) return;
+    const long fa = 2 * q;
+    const bool two = fa + 1 < n_frames;
+    const long fb = two ? fa + 1 : fa;
+    const int rows = (p.win_len + 63) >> 6;
+    float sa[8], sb[8];
+    {
+        const short *pa = pcm + (starts ? starts[fa] : (long long)p.hop * fa) + lane;
+        const short *pb = pcm + (starts ? starts[fb] : (long long)p.hop * fb) + lane;
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const bool in = r < rows - 1 || (r == rows - 1 && lane + 64 * r < p.win_len);
+            sa[r] = in ? (float)pa[64 * r] : 0.f;
+            sb[r] = in ? (float)pb[64 * r] : 0.f;
+        }
+    }
+    float ma[4], mb[4];
+    {
+        WaveTwiddles tw;
+        load_wave_twiddles(tw, table, lane);
+        float win[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) win[r] = reinterpret_cast<const float *>(p.window)[lane + 64 * r];
+        if (mfcc512_pair_mags(sa, sb, p.preemph, win, tw, lds, lane, ma, mb) && lane == 0)
+            redo[1 + atomicAdd(redo, 1)] = (int)q;
+    }
+    MelPiece mp;
+    load_mel_piece(mp, p, lane);
+    float *mag_a = reinterpret_cast<float *>(lds), *mag_b = mag_a + 320;
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+        const int k = lane + 64 * d, qk = k + (k >> 4);
+        mag_a[qk] = ma[d];
+        mag_b[qk] = mb[d];
+    }
+    logmel[0][lane] = 0.f;
+    logmel[1][lane] = 0.f;
+    wave_lds_fence();
+    mfcc_tail_x2(mag_a, mag_b, logmel, pieces, p, lane, mp, fa, fb, two, feats);
+}
+
 // (Tried for n_fft = 1024 too -- two frames per iteration through wave_fft512_x2, pair-owned |X|, tables in registers:
 // 206 registers = two waves per SIMD, 102 us per 65,536 frames against mfcc_x2_kernel's 97 us; at three waves, with
 // spills, 154 us.  profiles/r02_mfcc512_run.txt.  The 1024-point configurations stay with mfcc_x2_kernel.)
@@ -691,9 +751,14 @@ int launch_mfcc(hipStream_t s, const short *pcm, const long long *starts, long n
     if (JDSP_MFCC_RUN && p.seg_ok && p.bin_stride == 2 && p.win_len <= 512 && redo) {
         const long n_pairs = (n_frames + 1) / 2;
         if (hipMemsetAsync(redo, 0, sizeof(int), s) != hipSuccess) return -1;
-        const long slots = 1024L * JDSP_MFCC512_WAVES;              // resident waves of a 256-CU part
-        const long grid = n_pairs < slots ? n_pairs : slots;
-        hipLaunchKernelGGL(mfcc512_run_kernel, dim3((unsigned)grid), dim3(64), 0, s, pcm, starts, n_frames, p, table, feats, redo);
+        if (JDSP_MFCC512_ONE) {
+            hipLaunchKernelGGL(mfcc512_pair_kernel, dim3((unsigned)((n_pairs + 7) / 8 * 8)), dim3(64), 0, s, pcm, starts, n_frames, p,
+                               table, feats, redo);
+        } else {
+            const long slots = 1024L * JDSP_MFCC512_WAVES;          // resident waves of a 256-CU part
+            const long grid = n_pairs < slots ? n_pairs : slots;
+            hipLaunchKernelGGL(mfcc512_run_kernel, dim3((unsigned)grid), dim3(64), 0, s, pcm, starts, n_frames, p, table, feats, redo);
+        }
         hipLaunchKernelGGL(mfcc_kernel, dim3(1024), dim3(64), 0, s, pcm, starts, n_frames, p, table, feats, (const int *)redo);
     } else if (JDSP_MFCC_X2 && p.seg_ok) {
         const long grid = ((n_frames + 1) / 2 + 7) / 8 * 8;
