@@ -736,7 +736,9 @@ __global__ __launch_bounds__(64) void mfcc512_pair_kernel(const short *__restric
 
 // (Tried for n_fft = 1024 too -- two frames per iteration through wave_fft512_x2, pair-owned |X|, tables in registers:
 // 206 registers = two waves per SIMD, 102 us per 65,536 frames against mfcc_x2_kernel's 97 us; at three waves, with
-// spills, 154 us.  profiles/r02_mfcc512_run.txt.  The 1024-point configurations stay with mfcc_x2_kernel.)
+// spills, 154 us.  And the other way round -- ONE frame per wave with nothing kept, as mfcc512_pair_kernel does: 85
+// registers, five or six waves per SIMD, 119-134 us: twice the table loads per frame.  profiles/r02_mfcc512_run.txt.
+// The 1024-point configurations stay with mfcc_x2_kernel.)
 
 int launch_mfcc(hipStream_t s, const short *pcm, const long long *starts, long n_frames, const MfccDev &p,
                 const float2 *table, double *feats, int *redo)
