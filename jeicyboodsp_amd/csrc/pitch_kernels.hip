@@ -210,10 +210,92 @@ __global__ __launch_bounds__(64, JDSP_PITCH_WAVES) void pitch_run_kernel(const s
     }
 }
 
+// ONE block per wave, nothing kept between blocks (the form that paid for the 512-FFT MFCC kernel): tables loaded where
+// they are used.  JDSP_PITCH_ONE selects it (A/B in profiles/r02_pitch_run.txt).
+#ifndef JDSP_PITCH_ONE
+#define JDSP_PITCH_ONE 1
+#endif
+#ifndef JDSP_PITCH_ONE_WAVES
+#define JDSP_PITCH_ONE_WAVES 6
+#endif
+__global__ __launch_bounds__(64, JDSP_PITCH_ONE_WAVES) void pitch_one_kernel(const short *__restrict__ pcm, long n_blocks,
+                                                       const short *__restrict__ prev_block,
+                                                       const float2 *__restrict__ table, int *__restrict__ arg,
+                                                       float *__restrict__ rmax, float *__restrict__ autocorr)
+{
+    __shared__ __attribute__((aligned(16))) float2 lds[kWaveLdsComplex];
+    const int lane = threadIdx.x;
+    const long per_xcd = (gridDim.x + 7) >> 3;
+    const long b = (long)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (b >= n_blocks) return;
+    const unsigned int *p0 = b > 0 ? reinterpret_cast<const unsigned int *>(pcm + (b - 1) * 512)
+                                   : reinterpret_cast<const unsigned int *>(prev_block);
+    const unsigned int *p1 = reinterpret_cast<const unsigned int *>(pcm + b * 512);
+    float2 v[8], y[8];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const float2 a = unpack_i16x2(p0 ? p0[lane + 64 * r] : 0u), c = unpack_i16x2(p1[lane + 64 * r]);
+        v[r] = make_float2(0.5f * a.x, 0.5f * a.y);
+        v[r + 4] = make_float2(0.5f * c.x, 0.5f * c.y);
+    }
+    WaveTwiddles tw;
+    load_wave_twiddles(tw, table, lane);
+    wave_fft512<false>(v, lds, lane, tw);
+    wave_lds_fence();
+    {
+        PairTwiddles pw;
+        load_pair_twiddles(pw, table, lane);
+        float2 zr[5], ret[4];
+        pair_fetch_lds(v, lds, lane, zr);
+#pragma unroll
+        for (int d = 0; d < 5; d++) {
+            const float2 e = cadd_conj(v[d], zr[d]), o = csub_conj_mj(v[d], zr[d]);
+            const float2 t = cmul(pw.w[d], o);
+            const float2 lo = cadd(e, t), hi = csub(e, t);
+            const float pl = lo.x * lo.x + lo.y * lo.y, ph = hi.x * hi.x + hi.y * hi.y;
+            const float S = pl + ph, D = pl - ph;
+            const float rx = D * pw.w[d].x, ry = -D * pw.w[d].y;
+            y[d] = make_float2(S - ry, rx);
+            if (d < 4) ret[d] = make_float2(S + ry, rx);
+        }
+        pair_return_lds(ret, lds, lane, y);
+    }
+    wave_fft512<true>(y, lds, lane, tw);
+    float best = -INFINITY;
+    int at = 0x7fffffff;
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+        const int i0 = 2 * lane + 128 * d;
+        const float a = y[d].x * (1.0f / 1024.0f), c = y[d].y * (1.0f / 1024.0f);
+        if (autocorr) *reinterpret_cast<float2 *>(autocorr + b * 512 + i0) = make_float2(a, c);
+        const bool ta = (i0 > 100) & ((a > best) | ((a == best) & (i0 < at)));
+        best = ta ? a : best;
+        at = ta ? i0 : at;
+        const bool tc = (i0 + 1 > 100) & ((c > best) | ((c == best) & (i0 + 1 < at)));
+        best = tc ? c : best;
+        at = tc ? i0 + 1 : at;
+    }
+    JDSP_ARGMAX_STEP(0xB1, 0xf)
+    JDSP_ARGMAX_STEP(0x4E, 0xf)
+    JDSP_ARGMAX_STEP(0x141, 0xf)
+    JDSP_ARGMAX_STEP(0x140, 0xf)
+    JDSP_ARGMAX_STEP(0x142, 0xa)
+    JDSP_ARGMAX_STEP(0x143, 0xc)
+    if (lane == 63) {
+        arg[b] = at;
+        rmax[b] = best;
+    }
+}
+
 int launch_pitch(hipStream_t s, const short *pcm, long n_blocks, const short *prev_block, const float2 *table, int *arg,
                  float *rmax, float *autocorr)
 {
     if (n_blocks <= 0) return 0;
+    if (JDSP_PITCH_ONE) {
+        hipLaunchKernelGGL(pitch_one_kernel, dim3((unsigned)((n_blocks + 7) / 8 * 8)), dim3(64), 0, s, pcm, n_blocks, prev_block, table,
+                           arg, rmax, autocorr);
+        return hipGetLastError() == hipSuccess ? 0 : -1;
+    }
     if (JDSP_PITCH_RUN) {
         // one round of resident waves of a 256-CU part; never fewer than 4 blocks per wave
         const long slots = 1024L * JDSP_PITCH_WAVES;
