@@ -25,7 +25,12 @@ namespace jdsp {
 // A11.  frame = [zeros(512), block] because the keep buffer is never updated (SS:154 is
 // unreachable); s = (short)(x * w) truncates; E = sum s^2 / 1024; Z counts s[i]*x[i+1] < 0
 // (the next sample is not windowed yet, SS:139).  E > 700 <=> sum s^2 > 716800 exactly.
-constexpr int kVadBlocksPerWave = 8;     // the FP64 window slice (64 B per lane) is loaded once per wave
+#ifndef JDSP_VAD_BLOCKS_PER_WAVE
+#define JDSP_VAD_BLOCKS_PER_WAVE 4
+#endif
+// blocks per wave: the FP64 window slice (64 B per lane) is loaded once per wave.  4: 66 registers, seven waves per SIMD,
+// 13.0 us per 65,536 blocks; 8: 86 registers, 15.0 us; 2: 13.4; 1: 18.9; 16: 278 registers, 28.8 (profiles/r02_denoise_ab.txt)
+constexpr int kVadBlocksPerWave = JDSP_VAD_BLOCKS_PER_WAVE;
 
 // SPL = samples per lane = BLOCK_LEN / 64: 8 for the reference's 512-sample blocks (SS:54), 4 for 256-sample blocks
 // (FFT_PROCESSING_SIZE 512, BASELINE config 3 as worded).  dEnergy = sum / (2 BLOCK_LEN) > 700 (SS:143,147,48).
