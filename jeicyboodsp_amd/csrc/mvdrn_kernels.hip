@@ -428,18 +428,33 @@ __global__ __launch_bounds__(64) void mvdrn512_apply_kernel(const short *__restr
             const short *ca = pcm + (size_t)m0 * chan_stride, *cb = pcm + (size_t)(m1 < n_mics ? m1 : m0) * chan_stride;
             const short *pa = prev_in + (size_t)m0 * 512, *pb = prev_in + (size_t)(m1 < n_mics ? m1 : m0) * 512;
             float xa[8], xb[8];
+            if (j >= 1) {
+                // both blocks inside this call's buffer (wave-uniform): frame position pos is stream sample
+                // (j - 1) 256 + pos, one further from 255 on (the previous block's last sample is not in the frame),
+                // and 511 is the zero -- one load and one select per sample, no per-lane branches
+                const short *fa = ca + (j - 1) * 256 + lane, *fb = cb + (j - 1) * 256 + lane;
 #pragma unroll
-            for (int r = 0; r < 8; r++) {
-                const int pos = lane + 64 * r;        // frame position: < 255 previous block, 255..510 this block, 511 zero
-                float a = 0.f, b = 0.f;
-                if (pos < 255) {
-                    if (have_prev) { a = mvn512_sample(ca, n_blocks, pa, j - 1, pos); b = mvn512_sample(cb, n_blocks, pb, j - 1, pos); }
-                } else if (pos < 511) {
-                    a = (float)ca[j * 256 + pos - 255];
-                    b = (float)cb[j * 256 + pos - 255];
+                for (int r = 0; r < 8; r++) {
+                    const int pos = lane + 64 * r;
+                    const int off = 64 * r + (pos >= 255 ? 1 : 0) - (pos == 511 ? 1 : 0);      // (keeps the last lane in bounds)
+                    const float a = (float)fa[off], b = (float)fb[off];
+                    xa[r] = pos < 511 ? a : 0.f;
+                    xb[r] = (pos < 511 && m1 < n_mics) ? b : 0.f;
                 }
-                xa[r] = a;
-                xb[r] = m1 < n_mics ? b : 0.f;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 8; r++) {
+                    const int pos = lane + 64 * r;        // frame position: < 255 previous block, 255..510 this block, 511 zero
+                    float a = 0.f, b = 0.f;
+                    if (pos < 255) {
+                        if (have_prev) { a = mvn512_sample(ca, n_blocks, pa, j - 1, pos); b = mvn512_sample(cb, n_blocks, pb, j - 1, pos); }
+                    } else if (pos < 511) {
+                        a = (float)ca[j * 256 + pos - 255];
+                        b = (float)cb[j * 256 + pos - 255];
+                    }
+                    xa[r] = a;
+                    xb[r] = m1 < n_mics ? b : 0.f;
+                }
             }
             float2 A[5], B[5];
             mvn512_pair_spectra(xa, xb, tw, lds, lane, A, B);
