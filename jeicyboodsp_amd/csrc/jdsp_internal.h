@@ -73,6 +73,7 @@ struct DenoiseShard {
 };
 
 // BeamForming_MVDR_ver1.cpp's state between calls (device memory)
+constexpr int kMvdrTableVersions = 1024;     // 2-microphone MVDR: calls with fewer events than this get their weights from a table
 constexpr int kMvnChunks = 32;             // chunks the n-microphone covariance update cuts a call's events into
 
 struct MvdrState {
@@ -201,7 +202,7 @@ int ensure_stft1024_table_rect(jdsp_ctx *ctx);
 int launch_mvdr(hipStream_t s, const short *left, const short *right, long n_blocks, long calls_before,
                 const MvdrState *st_in, MvdrState *st_out, const int *events, const DenoisePlan *plan,
                 const int *ver_base, const unsigned long long *snap_mask, double *delta, double *rver,
-                const double2 *steer, const float2 *table, short *out, float *precast);
+                const double2 *steer, const float2 *table, short *out, float *precast, float4 *wtab);
 int launch_mvdr_corr_total(hipStream_t s, const short *left, const short *right, long n_blocks, const MvdrState *st_in,
                            const int *events, const DenoisePlan *plan, const float2 *table, double *delta, double *total);
 int launch_mvdr_apply(hipStream_t s, const short *left, const short *right, long n_blocks, long calls_before,
@@ -338,6 +339,7 @@ struct jdsp_mvdr {
     int *events = nullptr, *ev_n = nullptr, *ver_base = nullptr;
     unsigned long long *snap_mask = nullptr;
     double *delta = nullptr, *rver = nullptr;
+    float4 *wtab = nullptr;               // [kMvdrTableVersions][1024] per-version weights (mvdr_weights_kernel)
     // sharded (multi-GPU) run in progress
     long sh_ext0 = 0, sh_b0 = 0, sh_b1 = 0, sh_total = 0;
     const int16_t *sh_left = nullptr, *sh_right = nullptr;

@@ -39,6 +39,7 @@ int jdsp_mvdr_create(jdsp_ctx *ctx, double d_time, jdsp_mvdr **out)
     for (int i = 0; i < 2 && e == hipSuccess; i++) e = hipMalloc((void **)&h->st[i], sizeof(jdsp::MvdrState));
     if (e == hipSuccess) e = hipMalloc((void **)&h->plan, sizeof(jdsp::DenoisePlan));
     if (e == hipSuccess) e = hipMalloc((void **)&h->steer, sizeof(double2) * 1024);
+    if (e == hipSuccess) e = hipMalloc((void **)&h->wtab, sizeof(float4) * (size_t)jdsp::kMvdrTableVersions * 1024);
     if (e == hipSuccess) e = hipMalloc((void **)&h->w_vad, sizeof(w));
     if (e == hipSuccess) e = hipMalloc((void **)&h->sh_range, 4 * sizeof(int));
     if (e == hipSuccess) e = hipMalloc((void **)&h->sh_zero_run, sizeof(int));
@@ -68,6 +69,7 @@ int jdsp_mvdr_destroy(jdsp_mvdr *h)
         if (h->st[i]) (void)hipFree(h->st[i]);
     if (h->plan) (void)hipFree(h->plan);
     if (h->steer) (void)hipFree(h->steer);
+    if (h->wtab) (void)hipFree(h->wtab);
     if (h->w_vad) (void)hipFree(h->w_vad);
     if (h->sh_range) (void)hipFree(h->sh_range);
     if (h->sh_zero_run) (void)hipFree(h->sh_zero_run);
@@ -135,7 +137,7 @@ int jdsp_mvdr_process_dev(jdsp_mvdr *h, const int16_t *left_dev, const int16_t *
         jdsp::launch_run_plan(s, h->flags, n_blocks, &st_in->run_len, &st_out->run_len, 0, h->ver_base, h->snap_mask,
                               h->events, h->ev_n, h->plan) ||
         jdsp::launch_mvdr(s, left_dev, right_dev, n_blocks, h->calls, st_in, st_out, h->events, h->plan, h->ver_base,
-                          h->snap_mask, h->delta, h->rver, h->steer, ctx->stft1024_table, out_dev, precast_dev))
+                          h->snap_mask, h->delta, h->rver, h->steer, ctx->stft1024_table, out_dev, precast_dev, h->wtab))
         return fail(ctx, JDSP_EHIP, "mvdr launch", hipGetLastError());
     h->cur ^= 1;
     h->calls += n_blocks;

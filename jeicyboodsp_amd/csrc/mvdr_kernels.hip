@@ -289,10 +289,172 @@ __global__ __launch_bounds__(64) void mvdr_kernel(const short *__restrict__ left
     }
 }
 
+// ---- the same block with the spectra in registers and the weights out of a table --------------------------------
+// Where mvdr_kernel's time goes (profiles/r02_mvdr_pairs.txt): its ~230 LDS instructions per block (the weighted
+// 1024-bin spectrum written to LDS and read back four values per output bin for its Hermitian part, :193) are NOT the
+// bound -- the pair-owned form below halves them for no gain -- the per-bin FP64 weights are: 104 of 253 us, although
+// they change only when the matrix does.  So:
+//  * mvdr_weights_kernel: the weights of every (version, bin) of the call once, as float4 (the four values :175-178
+//    cast them to), when the call has at most kMvdrTableVersions - 1 events (otherwise the block kernel computes its
+//    own, as before: a stream that is mostly pauses has a new version for nearly every block);
+//  * mvdr_pairs_kernel: lane l owns the bins m, m + 512 of m = l + 64 d, d < 5 (frame_io.h, pair-owned split);
+//    X[1024 - m] = conj X[m] and X[512 - m] = conj X[m + 512] of a real frame are in the same lane, so the four weighted
+//    values an output pair needs (bins m, 1024 - m, m + 512, 512 - m, each with its own steering phase) are formed
+//    where they are used, the Hermitian parts and the pre-split follow in registers, and only the mirror operands and
+//    Z'[512 - m] cross lanes.
+#ifndef JDSP_MVDR_PAIRS
+#define JDSP_MVDR_PAIRS 1
+#endif
+struct MvdrInv { double i00, i01, i10, i11; };
+
+__device__ __forceinline__ MvdrInv mvdr_inverse(const double *__restrict__ R)     // mxAutoCorr.inverse() (:170)
+{
+    const double a = R[0], b = R[1], c = R[2], d = R[3];
+    const double invdet = 1.0 / (a * d - b * c);
+    MvdrInv iv;
+    iv.i00 = d * invdet; iv.i01 = -b * invdet; iv.i10 = -c * invdet; iv.i11 = a * invdet;
+    return iv;
+}
+
+// one bin's weights: w = R^-1 c / (c^H R^-1 c), c = (1, s1) (:164-171), as the four floats of :175-178
+__device__ __forceinline__ float4 mvdr_bin_weights(const MvdrInv &iv, double2 s1)
+{
+    const double w0r = iv.i00 + iv.i01 * s1.x, w0i = iv.i01 * s1.y;          // R^-1 c
+    const double w1r = iv.i10 + iv.i11 * s1.x, w1i = iv.i11 * s1.y;
+    const double dr = w0r + (s1.x * w1r + s1.y * w1i);                        // c^H (R^-1 c)
+    const double di = w0i + (s1.x * w1i - s1.y * w1r);
+    const double dn = dr * dr + di * di;
+    double rn = __builtin_amdgcn_rcp(dn);                                     // v_rcp_f64 + one Newton step; 1 / 0 as the division gives it
+    rn = fma(rn, fma(-dn, rn, 1.0), rn);
+    rn = dn == 0.0 ? (double)INFINITY : rn;
+    const double t0r = (w0r * dr + w0i * di) * rn, t0i = (w0i * dr - w0r * di) * rn;
+    const double t1r = (w1r * dr + w1i * di) * rn, t1i = (w1i * dr - w1r * di) * rn;
+    return make_float4((float)t0r, (float)-t0i, (float)t1r, (float)-t1i);     // lw0, lw1, rw0, rw1: the conjugates
+}
+
+// :180-185 -- the imaginary part is formed from the ALREADY OVERWRITTEN real part
+__device__ __forceinline__ float2 mvdr_apply_weights(float4 w, float2 L, float2 Rr)
+{
+    L.x = L.x * w.x - L.y * w.y;
+    L.y = L.x * w.y + L.y * w.x;
+    Rr.x = Rr.x * w.z - Rr.y * w.w;
+    Rr.y = Rr.x * w.w + Rr.y * w.z;
+    return make_float2(L.x + Rr.x, L.y + Rr.y);
+}
+
+__global__ __launch_bounds__(256) void mvdr_weights_kernel(const DenoisePlan *__restrict__ plan, const double *__restrict__ rver,
+                                                           const double2 *__restrict__ steer, float4 *__restrict__ wtab)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int ver = idx >> 10, bin = idx & 1023;
+    const int n_events = plan->n_events;
+    if (n_events >= kMvdrTableVersions || ver > n_events) return;          // too many versions: the block kernel computes
+    wtab[idx] = mvdr_bin_weights(mvdr_inverse(rver + (size_t)ver * 4), steer[bin]);
+}
+
+__global__ __launch_bounds__(64) void mvdr_pairs_kernel(const short *__restrict__ left, const short *__restrict__ right,
+                                                        long n_blocks, long calls_before,
+                                                        const MvdrState *__restrict__ st_in, MvdrState *st_out,
+                                                        const int *__restrict__ ver_base,
+                                                        const unsigned long long *__restrict__ snap_mask,
+                                                        const double *__restrict__ rver, const double2 *__restrict__ steer,
+                                                        const float2 *__restrict__ table, short *__restrict__ out,
+                                                        float *__restrict__ precast, DenoiseShard sh,
+                                                        const DenoisePlan *__restrict__ plan, const float4 *__restrict__ wtab)
+{
+    __shared__ __attribute__((aligned(16))) float2 lds[kWaveLdsComplex];
+    __shared__ __attribute__((aligned(16))) unsigned int stage32[528];
+    const int lane = threadIdx.x;
+    const long per_xcd = (gridDim.x + 7) >> 3;
+    const long j = (long)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (j >= n_blocks) return;
+    WaveTwiddles tw;
+    load_wave_twiddles(tw, table, lane);
+    PairTwiddles pw;
+    load_pair_twiddles(pw, table, lane);
+    const bool have_prev = calls_before + j > 0;
+    const long jp = have_prev ? j - 1 : -2;          // keep buffer of a stream's very first block: zeros (:130-131)
+
+    float2 llo[5], lhi[5], rlo[5], rhi[5], v[8], zr[5];
+    mvdr_frame_pairs(stage32, lane, mvdr_load_block(left, n_blocks, st_in->prev_l, jp, lane),
+                     mvdr_load_block(left, n_blocks, st_in->prev_l, j, lane), v, 0.5f);
+    wave_fft512<false>(v, lds, lane, tw);
+    wave_lds_fence();
+    pair_fetch_lds(v, lds, lane, zr);
+#pragma unroll
+    for (int d = 0; d < 5; d++) {
+        const float2 e = cadd_conj(v[d], zr[d]), o = csub_conj_mj(v[d], zr[d]);
+        const float2 t = cmul(pw.w[d], o);
+        llo[d] = cadd(e, t);
+        lhi[d] = csub(e, t);
+    }
+    mvdr_frame_pairs(stage32, lane, mvdr_load_block(right, n_blocks, st_in->prev_r, jp, lane),
+                     mvdr_load_block(right, n_blocks, st_in->prev_r, j, lane), v, 0.5f);
+    wave_fft512<false>(v, lds, lane, tw);
+    wave_lds_fence();
+    pair_fetch_lds(v, lds, lane, zr);
+#pragma unroll
+    for (int d = 0; d < 5; d++) {
+        const float2 e = cadd_conj(v[d], zr[d]), o = csub_conj_mj(v[d], zr[d]);
+        const float2 t = cmul(pw.w[d], o);
+        rlo[d] = cadd(e, t);
+        rhi[d] = csub(e, t);
+    }
+    // the matrix in effect at this block
+    int ver = version_of(ver_base, snap_mask, j + sh.ver_block_off);
+    if (sh.ver_row_off) ver -= *sh.ver_row_off;
+    if (ver < 0) ver = 0;
+    const bool tabled = wtab && plan->n_events < kMvdrTableVersions;       // wave-uniform
+    const float4 *wrow = wtab + (size_t)ver * 1024;
+    MvdrInv iv = {0.0, 0.0, 0.0, 0.0};
+    if (!tabled) iv = mvdr_inverse(rver + (size_t)ver * 4);
+    float2 y[8], ret[4];
+#pragma unroll
+    for (int d = 0; d < 5; d++) {
+        const int m = lane + 64 * d;
+        const int b1 = (1024 - m) & 1023, b3 = 512 - m;
+        float4 w0, w1, w2, w3;
+        if (tabled) { w0 = wrow[m]; w1 = wrow[b1]; w2 = wrow[m + 512]; w3 = wrow[b3]; }
+        else {
+            w0 = mvdr_bin_weights(iv, steer[m]); w1 = mvdr_bin_weights(iv, steer[b1]);
+            w2 = mvdr_bin_weights(iv, steer[m + 512]); w3 = mvdr_bin_weights(iv, steer[b3]);
+        }
+        const float2 cl = make_float2(llo[d].x, -llo[d].y), cr = make_float2(rlo[d].x, -rlo[d].y);   // X[1024 - m] = conj X[m]
+        const float2 ch = make_float2(lhi[d].x, -lhi[d].y), cs = make_float2(rhi[d].x, -rhi[d].y);   // X[512 - m] = conj X[m + 512]
+        const float2 a0 = mvdr_apply_weights(w0, llo[d], rlo[d]), a1 = mvdr_apply_weights(w1, cl, cr);
+        const float2 g0 = mvdr_apply_weights(w2, lhi[d], rhi[d]), g1 = mvdr_apply_weights(w3, ch, cs);
+        // The reference keeps only the real part of the inverse transform (:193) = the inverse transform of the
+        // Hermitian part of the weighted spectrum.
+        const float2 ylo = make_float2(0.5f * (a0.x + a1.x), 0.5f * (a0.y - a1.y));
+        const float2 yhi = make_float2(0.5f * (g0.x + g1.x), 0.5f * (g0.y - g1.y));
+        if (d < 4) presplit_inv_pair(ylo, yhi, pw.w[d], y[d], ret[d]);
+        else y[d] = presplit_inv_reg(ylo, yhi, pw.w[d]);
+    }
+    pair_return_lds(ret, lds, lane, y);
+    wave_fft512<true>(y, lds, lane, tw);
+
+    const long first_emit = sh.emit_from;                           // :201-204: the first call's block is dropped
+    if (j >= first_emit && j < sh.emit_to) {
+        short *o = out + (j - first_emit) * 512;
+        float *pc = precast ? precast + (j - first_emit) * 512 : nullptr;
+#pragma unroll
+        for (int dd = 0; dd < 8; dd++) {
+            const int i0 = 2 * lane + 128 * dd - 511;                // :193 rgsOutputBuffer[i] = y[i + 511] / 1024
+            const float s0 = y[dd].x * (1.0f / 1024.0f), s1 = y[dd].y * (1.0f / 1024.0f);
+            if (i0 >= 0 && i0 < 512) { o[i0] = (short)cast_i16_bits(s0); if (pc) pc[i0] = s0; }
+            if (i0 + 1 >= 0 && i0 + 1 < 512) { o[i0 + 1] = (short)cast_i16_bits(s1); if (pc) pc[i0 + 1] = s1; }
+        }
+    }
+    if (j == n_blocks - 1) {
+        reinterpret_cast<u32x4 *>(st_out->prev_l)[lane] = reinterpret_cast<const u32x4 *>(left + j * 512)[lane];
+        reinterpret_cast<u32x4 *>(st_out->prev_r)[lane] = reinterpret_cast<const u32x4 *>(right + j * 512)[lane];
+    }
+}
+
 int launch_mvdr(hipStream_t s, const short *left, const short *right, long n_blocks, long calls_before,
                 const MvdrState *st_in, MvdrState *st_out, const int *events, const DenoisePlan *plan,
                 const int *ver_base, const unsigned long long *snap_mask, double *delta, double *rver,
-                const double2 *steer, const float2 *table, short *out, float *precast)
+                const double2 *steer, const float2 *table, short *out, float *precast, float4 *wtab)
 {
     if (n_blocks <= 0) return 0;
     const long g1 = n_blocks < 2048 ? n_blocks : 2048;
@@ -306,8 +468,16 @@ int launch_mvdr(hipStream_t s, const short *left, const short *right, long n_blo
     sh.emit_from = calls_before >= 1 ? 0 : 1;
     sh.emit_to = n_blocks;
     const long grid = (n_blocks + 7) / 8 * 8;
+#if JDSP_MVDR_PAIRS
+    if (wtab)                                            // wtab: kMvdrTableVersions x 1024 float4, or NULL (no table)
+        hipLaunchKernelGGL(mvdr_weights_kernel, dim3(kMvdrTableVersions * 1024 / 256), dim3(256), 0, s, plan, rver, steer, wtab);
+    hipLaunchKernelGGL(mvdr_pairs_kernel, dim3((unsigned)grid), dim3(64), 0, s, left, right, n_blocks, calls_before, st_in,
+                       st_out, ver_base, snap_mask, rver, steer, table, out, precast, sh, plan, (const float4 *)wtab);
+#else
+    (void)wtab;
     hipLaunchKernelGGL(mvdr_kernel, dim3((unsigned)grid), dim3(64), 0, s, left, right, n_blocks, calls_before, st_in,
                        st_out, ver_base, snap_mask, rver, steer, table, out, precast, sh);
+#endif
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
