@@ -672,6 +672,9 @@ __device__ __forceinline__ void denoise_frame_nreg(const unsigned int *raw, cons
 #ifndef JDSP_DENOISE_PAIRS
 #define JDSP_DENOISE_PAIRS 1
 #endif
+#ifndef JDSP_DENOISE_ABLATE
+#define JDSP_DENOISE_ABLATE 0       // timing-only ablations of denoise_frame_pairs (tools/build_variant.sh): wrong results
+#endif
 struct NoisePairRegs { float lo[5], hi[5]; };
 template <int MODE>
 __device__ __forceinline__ void load_noise_pair_regs(NoisePairRegs &n, const float *__restrict__ row, int lane)
@@ -713,22 +716,38 @@ __device__ __forceinline__ void denoise_frame_pairs(const unsigned int *raw, con
     wave_fft512<false>(v, lds, lane, t.tw);
     float2 zr[5], ret[4];
     wave_lds_fence();                                            // the transform's last exchange reads are done
+#if JDSP_DENOISE_ABLATE & 2                                           /* timing-only: no mirror fetch / return */
+#pragma unroll
+    for (int d = 0; d < 5; d++) zr[d] = v[7 - d];
+#else
     pair_fetch_lds(v, lds, lane, zr);
+#endif
 #pragma unroll
     for (int d = 0; d < 5; d++) {
         const float2 e = cadd_conj(v[d], zr[d]);
         const float2 o = csub_conj_mj(v[d], zr[d]);
         const float2 p = cmul(pw.w[d], o);
+#if JDSP_DENOISE_ABLATE & 1                                           /* timing-only: no gain */
+        const float2 lo = cadd(e, p), hi = csub(e, p);
+#else
         const float2 lo = apply_gain_scaled<MODE>(cadd(e, p), n.lo[d]);      // Y[m] / 1024
         const float2 hi = apply_gain_scaled<MODE>(csub(e, p), n.hi[d]);      // Y[m + 512] / 1024
+#endif
         if (d < 4) {
             presplit_inv_pair(lo, hi, pw.w[d], y[d], ret[d]);
         } else {
             y[d] = presplit_inv_reg(lo, hi, pw.w[d]);
         }
     }
+#if JDSP_DENOISE_ABLATE & 2
+#pragma unroll
+    for (int d = 5; d < 8; d++) y[d] = ret[d - 5];
+#else
     pair_return_lds(ret, lds, lane, y);
+#endif
+#if !(JDSP_DENOISE_ABLATE & 4)                                        /* 4, timing-only: no inverse transform */
     wave_fft512<true>(y, lds, lane, t.tw);
+#endif
     wave_lds_fence();
 }
 
