@@ -368,3 +368,36 @@ def test_small_calls_keep_the_sequential_average_bit_for_bit(eng):
     assert np.array_equal(a.noise(), b.noise())
     a.close()
     b.close()
+
+
+@pytest.mark.parametrize("n_events_target", [63, 64, 65, 66, 4090, 4101, 4104, 4200])
+def test_noise_average_chunk_geometry_edges(eng, oracle, n_events_target):
+    """Event counts on both sides of the chunked average's boundaries: 64 events (one chunk per group / several), 4,096
+    (one event per chunk / two).  One long quiet run gives n - 1 events (run length >= 2 from its second block on)."""
+    n_quiet = n_events_target + 1
+    n_blocks = n_quiet + 6
+    pcm = speechlike(900 + n_events_target, n_blocks, pattern=[n_quiet, 6])
+    o_out, o_pre, flags, noises, ver = oracle.denoise_trace(0, pcm)
+    # the quiet stretch is Gaussian: a handful of its blocks may come out as voice and split the run -- what matters is
+    # that the number of events is at the boundary or within a few of it
+    n_events = int(sum(max(0, r - 1) for r in _runs_of_zero(flags)))
+    assert abs(n_events - n_events_target) <= 12
+    d = eng.denoiser(0)
+    out, pre = d.process(pcm, want_precast=True)
+    check_stream(out, pre, o_out, o_pre)
+    assert np.abs(d.noise() - noises[-1]).max() <= TOL * max(noises[-1].max(), 1.0)
+    d.close()
+
+
+def _runs_of_zero(flags):
+    runs, n = [], 0
+    for f in flags:
+        if f == 0:
+            n += 1
+        else:
+            if n:
+                runs.append(n)
+            n = 0
+    if n:
+        runs.append(n)
+    return runs

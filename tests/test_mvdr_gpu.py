@@ -169,3 +169,16 @@ def test_pause_heavy_stream_uses_the_parallel_prefix(eng, oracle):
     scale = max(o_corr[0], o_corr[3], 1.0)
     assert abs(c[0] - o_corr[0]) <= TOL * scale and abs(c[3] - o_corr[3]) <= TOL * scale
     m.close()
+
+
+@pytest.mark.parametrize("n_quiet", [1021, 1024, 1027])
+def test_weight_table_boundary(eng, oracle, n_quiet):
+    """Calls with fewer than 1,024 events read their per-bin weights from the per-version table, calls with more compute
+    them per block: both sides of that boundary against the oracle (one quiet run of n blocks = n - 1 or n events)."""
+    nb = n_quiet + 40
+    L, R = stereo(50 + n_quiet, nb, quiet=((20, n_quiet),))
+    o_out, o_pre, o_corr, trace = oracle.mvdr_stream(L, R, 2.5e-4)
+    m = eng.mvdr(2.5e-4)
+    out, pre = m.process(L, R, want_precast=True)
+    check(out, pre, o_out, o_pre)
+    m.close()

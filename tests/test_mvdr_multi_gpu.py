@@ -170,3 +170,15 @@ def test_many_estimation_frames_per_call(eng, oracle, n_fft):
     out, pre = m.process(pcm, want_precast=True)
     check(out, pre, o_out, o_pre)
     m.close()
+
+
+@pytest.mark.parametrize("n_quiet", [31, 32, 33, 34, 65])
+def test_covariance_chunk_geometry_edges(eng, oracle, n_quiet):
+    """Event counts on both sides of the chunked update's boundary (32 chunks: one event per chunk up to 32, two from 33)."""
+    n_blocks = n_quiet + 12
+    pcm, _, delays = array_scene(70 + n_quiet, 3, n_blocks, quiet=((4, n_quiet),))
+    o_out, o_pre = oracle.mvdrn_stream(pcm, delays, 1e-3)
+    m = eng.mvdr_multi(3, delays, 1e-3)
+    out, pre = m.process(pcm, want_precast=True)
+    check(out, pre, o_out, o_pre)
+    m.close()
