@@ -290,14 +290,31 @@ __global__ __launch_bounds__(1024) void plan_kernel(const unsigned char *__restr
             ver_base[a >> 6] = carry_sn + cnt_sn[t] - ns;
             snap_mask[a >> 6] = S;
         }
-        if (E) {
-            int eo = carry_ev + cnt_ev[t] - ne;
-            for (unsigned long long rest = E; rest; rest &= rest - 1ull) {
-                const int i = __ffsll((long long)rest) - 1;
-                const unsigned long long below = V & ((1ull << i) - 1ull);    // voice bits before i (bit i is noise)
-                events[eo] = (int)(a + i);
-                ev_n[eo] = below ? i - (63 - __clzll((long long)below)) : r_start + i + 1;
-                eo++;
+        {
+            // The event list, written by the wave together: for each of its 64 slices in turn, lane i takes bit i of the
+            // slice's event mask.  (Every thread walking its own slice's bits wrote up to 64 scattered 4-byte stores
+            // per lane and instruction: 68 us of this kernel on an all-quiet 65,536-block call, now a handful of
+            // contiguous stores per slice.)
+            const int eo_mine = carry_ev + cnt_ev[t] - ne;
+            const int lane = t & 63;
+            const long a_wave = tile0 + (long)(t - lane) * 64;
+            unsigned long long todo = __ballot(E != 0ull);                  // slices of this wave that hold events
+            for (; todo; todo &= todo - 1ull) {
+                const int sl = __ffsll((long long)todo) - 1;                   // wave-uniform
+                const unsigned int e_lo = __builtin_amdgcn_readlane((int)(unsigned int)E, sl);
+                const unsigned int e_hi = __builtin_amdgcn_readlane((int)(unsigned int)(E >> 32), sl);
+                const unsigned long long Es = ((unsigned long long)e_hi << 32) | e_lo;
+                const unsigned int v_lo = __builtin_amdgcn_readlane((int)(unsigned int)V, sl);
+                const unsigned int v_hi = __builtin_amdgcn_readlane((int)(unsigned int)(V >> 32), sl);
+                const unsigned long long Vs = ((unsigned long long)v_hi << 32) | v_lo;
+                const int rs = __builtin_amdgcn_readlane(r_start, sl), eos = __builtin_amdgcn_readlane(eo_mine, sl);
+                if ((Es >> lane) & 1ull) {
+                    const unsigned long long lower = (1ull << lane) - 1ull;
+                    const int idx = eos + __popcll(Es & lower);
+                    const unsigned long long below = Vs & lower;            // voice bits before this one (this bit is noise)
+                    events[idx] = (int)(a_wave + (long)sl * 64 + lane);
+                    ev_n[idx] = below ? lane - (63 - __clzll((long long)below)) : rs + lane + 1;
+                }
             }
         }
         __syncthreads();
@@ -442,8 +459,10 @@ __global__ __launch_bounds__(64) void noise_accum_kernel(const short *__restrict
         const float h = n >= 3 ? 0.5f : 1.0f;                    // SS:182-187
 #pragma unroll
         for (int d = 0; d < 8; d++) {
-            blo[d] = (blo[d] + sqrtf(lo[d].x * lo[d].x + lo[d].y * lo[d].y)) * h;
-            bhi[d] = (bhi[d] + sqrtf(hi[d].x * hi[d].x + hi[d].y * hi[d].y)) * h;
+            // hardware square root (1 ulp; sqrtf() expands to ~12 instructions of scaling and fix-up per value, a third
+            // of this loop)
+            blo[d] = (blo[d] + __builtin_amdgcn_sqrtf(lo[d].x * lo[d].x + lo[d].y * lo[d].y)) * h;
+            bhi[d] = (bhi[d] + __builtin_amdgcn_sqrtf(hi[d].x * hi[d].x + hi[d].y * hi[d].y)) * h;
         }
         alpha *= h;
         if (n == latch_run) {                                    // SS:189-193
@@ -473,12 +492,23 @@ __global__ __launch_bounds__(1024) void noise_combine_kernel(const DenoisePlan *
     const int per_group = (cg.n_chunks + 63) >> 6;
     const int c0 = g * per_group < cg.n_chunks ? g * per_group : cg.n_chunks;
     const int c1 = c0 + per_group < cg.n_chunks ? c0 + per_group : cg.n_chunks;
+    // The two walks over the group's chunks are chains of one FMA per chunk -- but of one LOAD per chunk too, and a
+    // load at a time is a memory latency per chunk (49 us for 4,096 chunks: profiles/r02_denoise_events.txt).  The
+    // loads do not depend on the chain: sixteen chunks' values are requested together, then applied in order.
+    constexpr int kBatch = 16;
     {
         float a = 1.0f, b = 0.0f;                                 // this group's chunks composed
-        for (int c = c0; c < c1; c++) {
-            const float ac = acc.chunk_alpha[c];
-            b = ac * b + acc.chunk_beta[(size_t)c * 1024 + bin];
-            a *= ac;
+        for (int cb = c0; cb < c1; cb += kBatch) {
+            float al[kBatch], be[kBatch];
+#pragma unroll
+            for (int u = 0; u < kBatch; u++) {
+                const int c = cb + u < c1 ? cb + u : c1 - 1;
+                al[u] = acc.chunk_alpha[c];
+                be[u] = acc.chunk_beta[(size_t)c * 1024 + bin];
+            }
+#pragma unroll
+            for (int u = 0; u < kBatch; u++)
+                if (cb + u < c1) { b = al[u] * b + be[u]; a *= al[u]; }
         }
         ga[g][bl] = a;
         gb[g][bl] = b;
@@ -486,9 +516,20 @@ __global__ __launch_bounds__(1024) void noise_combine_kernel(const DenoisePlan *
     __syncthreads();
     float A = st_in->avg[bin];
     for (int q = 0; q < g; q++) A = ga[q][bl] * A + gb[q][bl];   // the average entering this group
-    for (int c = c0; c < c1; c++) {
-        acc.a_start[(size_t)c * 1024 + bin] = A;
-        A = acc.chunk_alpha[c] * A + acc.chunk_beta[(size_t)c * 1024 + bin];
+    for (int cb = c0; cb < c1; cb += kBatch) {
+        float al[kBatch], be[kBatch];
+#pragma unroll
+        for (int u = 0; u < kBatch; u++) {
+            const int c = cb + u < c1 ? cb + u : c1 - 1;
+            al[u] = acc.chunk_alpha[c];
+            be[u] = acc.chunk_beta[(size_t)c * 1024 + bin];
+        }
+#pragma unroll
+        for (int u = 0; u < kBatch; u++)
+            if (cb + u < c1) {
+                acc.a_start[(size_t)(cb + u) * 1024 + bin] = A;
+                A = al[u] * A + be[u];
+            }
     }
     if (g == 63) st_out->avg[bin] = A;                           // groups past the last chunk are identities
     if (g == 0) noise_rows[bin] = st_in->noise[bin];             // row 0: the estimate carried in
@@ -1325,8 +1366,8 @@ __global__ __launch_bounds__(64) void noise_accum512_kernel(const short *__restr
             const int k = lane + 64 * q;
             const float2 zk = lds[k], zm = lds[512 - k];
             const float2 A = cadd_conj(zk, zm), B = csub_conj_mj(zk, zm);
-            ma[q] = sqrtf(A.x * A.x + A.y * A.y);
-            mb[q] = sqrtf(B.x * B.x + B.y * B.y);
+            ma[q] = __builtin_amdgcn_sqrtf(A.x * A.x + A.y * A.y);      // hardware square root, 1 ulp (see noise_accum_kernel)
+            mb[q] = __builtin_amdgcn_sqrtf(B.x * B.x + B.y * B.y);
         }
         const float2 z = lds[256];
         wave_lds_fence();

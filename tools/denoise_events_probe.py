@@ -51,6 +51,7 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--only-mode", type=int, default=-1)
     ap.add_argument("--mvdr", action="store_true", help="the two MVDR chains instead (their VAD is the energy test alone)")
+    ap.add_argument("--case", type=int, default=-1, help="only the i-th pause setting (0..4) of the 1024-point denoiser (for rocprofv3)")
     a = ap.parse_args()
     eng = jeicyboodsp_amd.Engine(0)
     rng = np.random.default_rng(5)
@@ -80,7 +81,11 @@ def main():
                 mv.close()
         return
     for n_fft, block in ((1024, 512), (512, 256)):
-        for pause_frac, mean_run in ((0.0, 0), (0.1, 20), (0.5, 40), (0.5, 6), (1.0, 1 << 30)):
+        if a.case >= 0 and n_fft != 1024:
+            continue
+        for ci, (pause_frac, mean_run) in enumerate(((0.0, 0), (0.1, 20), (0.5, 40), (0.5, 6), (1.0, 1 << 30))):
+            if a.case >= 0 and ci != a.case:
+                continue
             x, n_quiet = stream(rng, B, block, pause_frac, mean_run)
             bufs = [torch.from_numpy(x).cuda() for _ in range(6)]
             for mode in (0, 1):
