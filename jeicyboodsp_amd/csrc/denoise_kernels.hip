@@ -479,17 +479,22 @@ __global__ __launch_bounds__(64) void noise_accum_kernel(const short *__restrict
     if (lane == 0) acc.chunk_alpha[chunk] = alpha;
 }
 
-// grid: n_bins / 16 workgroups of 1024 threads = 16 bins x 64 chunk groups; accum_grid = noise_accum's grid size
+// grid: n_bins / kCombineBins workgroups of 1024 threads = kCombineBins bins x kCombineGroups chunk groups;
+// accum_grid = noise_accum's grid size
+#ifndef JDSP_COMBINE_BINS
+#define JDSP_COMBINE_BINS 16
+#endif
+constexpr int kCombineBins = JDSP_COMBINE_BINS, kCombineGroups = 1024 / JDSP_COMBINE_BINS;
 __global__ __launch_bounds__(1024) void noise_combine_kernel(const DenoisePlan *__restrict__ plan,
                                                              const DenoiseState *__restrict__ st_in, DenoiseState *st_out,
                                                              NoiseAccum acc, float *__restrict__ noise_rows, int accum_grid)
 {
-    __shared__ float ga[64][16], gb[64][16];
-    const int bl = threadIdx.x & 15, g = threadIdx.x >> 4;
-    const int bin = blockIdx.x * 16 + bl;
+    __shared__ float ga[kCombineGroups][kCombineBins], gb[kCombineGroups][kCombineBins];
+    const int bl = threadIdx.x % kCombineBins, g = threadIdx.x / kCombineBins;
+    const int bin = blockIdx.x * kCombineBins + bl;
     const int n_snap = plan->n_snap;
     const ChunkGeom cg = chunk_geom(plan->n_events, accum_grid);
-    const int per_group = (cg.n_chunks + 63) >> 6;
+    const int per_group = (cg.n_chunks + kCombineGroups - 1) / kCombineGroups;
     const int c0 = g * per_group < cg.n_chunks ? g * per_group : cg.n_chunks;
     const int c1 = c0 + per_group < cg.n_chunks ? c0 + per_group : cg.n_chunks;
     // The two walks over the group's chunks are chains of one FMA per chunk -- but of one LOAD per chunk too, and a
@@ -531,10 +536,10 @@ __global__ __launch_bounds__(1024) void noise_combine_kernel(const DenoisePlan *
                 A = al[u] * A + be[u];
             }
     }
-    if (g == 63) st_out->avg[bin] = A;                           // groups past the last chunk are identities
+    if (g == kCombineGroups - 1) st_out->avg[bin] = A;           // groups past the last chunk are identities
     if (g == 0) noise_rows[bin] = st_in->noise[bin];             // row 0: the estimate carried in
     __syncthreads();                                             // a_start is read back by other threads of this workgroup
-    for (int r = 1 + g; r <= n_snap; r += 64) {
+    for (int r = 1 + g; r <= n_snap; r += kCombineGroups) {
         float *row = noise_rows + (size_t)r * 1024 + bin;
         *row = acc.lat_alpha[r] * acc.a_start[(size_t)acc.lat_chunk[r] * 1024 + bin] + *row;
     }
@@ -1193,7 +1198,7 @@ int launch_noise_estimate(hipStream_t s, const short *pcm, long n_blocks, const 
     if (n_blocks > 0)
         hipLaunchKernelGGL(noise_accum_kernel, dim3((unsigned)grid), dim3(64), 0, s, pcm, n_blocks, st_in, events, ev_n, plan,
                            ver_base, snap_mask, table, acc, noise_rows, 10);
-    hipLaunchKernelGGL(noise_combine_kernel, dim3(1024 / 16), dim3(1024), 0, s, plan, st_in, st_out, acc, noise_rows, grid);
+    hipLaunchKernelGGL(noise_combine_kernel, dim3(1024 / kCombineBins), dim3(1024), 0, s, plan, st_in, st_out, acc, noise_rows, grid);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
@@ -1707,7 +1712,7 @@ int launch_noise_estimate512(hipStream_t s, const short *pcm, long n_blocks, con
         hipLaunchKernelGGL(noise_accum512_kernel, dim3((unsigned)grid), dim3(64), 0, s, pcm, n_blocks, st_in, events, ev_n,
                            plan, ver_base, snap_mask, table, win512, acc, noise_rows, 10);
     // bins 0..511 only (rows keep the 1024-float pitch of the 1024-point path)
-    hipLaunchKernelGGL(noise_combine_kernel, dim3(512 / 16), dim3(1024), 0, s, plan, st_in, st_out, acc, noise_rows, grid);
+    hipLaunchKernelGGL(noise_combine_kernel, dim3(512 / kCombineBins), dim3(1024), 0, s, plan, st_in, st_out, acc, noise_rows, grid);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
