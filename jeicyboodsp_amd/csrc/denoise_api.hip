@@ -5,7 +5,7 @@ using jdsp::fail;
 
 static void free_workspace(jdsp_denoise *h)
 {
-    void *p[] = {h->flags, h->ev_n, h->ver_base, h->snap_mask, h->events, h->dbg_energy, h->dbg_zcr, h->mag, h->rows,
+    void *p[] = {h->flags, h->ev_n, h->ver_base, h->snap_mask, h->events, h->dbg_energy, h->dbg_zcr, h->rows,
                  h->acc.lat_alpha, h->acc.lat_chunk, h->acc.chunk_alpha, h->acc.chunk_beta, h->acc.a_start};
     for (void *q : p)
         if (q) (void)hipFree(q);
@@ -14,12 +14,11 @@ static void free_workspace(jdsp_denoise *h)
     h->snap_mask = nullptr;
     h->dbg_energy = nullptr;
     h->dbg_zcr = nullptr;
-    h->mag = h->rows = nullptr;
+    h->rows = nullptr;
     h->acc.lat_alpha = h->acc.chunk_alpha = h->acc.chunk_beta = h->acc.a_start = nullptr;
     h->acc.lat_chunk = nullptr;
     h->cap_rows = 0;
     h->cap_blocks = 0;
-    h->cap_mag = 0;
 }
 
 extern "C" {
@@ -134,21 +133,19 @@ long jdsp_denoise_blocks_out(const jdsp_denoise *h, long n_blocks)
     return n_blocks > first_emit ? n_blocks - first_emit : 0;
 }
 
-static int reserve2(jdsp_denoise *h, long max_blocks, long mag_blocks);
+static int reserve2(jdsp_denoise *h, long max_blocks);
 
 int jdsp_denoise_reserve(jdsp_denoise *h, long max_blocks)
 {
     if (!h || max_blocks < 0) return JDSP_EINVAL;
-    return reserve2(h, max_blocks, 0);
+    return reserve2(h, max_blocks);
 }
 
-// max_blocks: blocks the run-length plan covers; mag_blocks: blocks whose magnitudes this GPU may hold
-static int reserve2(jdsp_denoise *h, long max_blocks, long mag_blocks)
+// max_blocks: blocks the run-length plan covers (a sharded run: the whole stream's)
+static int reserve2(jdsp_denoise *h, long max_blocks)
 {
     jdsp_ctx *ctx = h->ctx;
-    if (max_blocks <= h->cap_blocks && mag_blocks <= h->cap_mag) return JDSP_OK;
-    if (max_blocks < h->cap_blocks) max_blocks = h->cap_blocks;
-    if (mag_blocks < h->cap_mag) mag_blocks = h->cap_mag;
+    if (max_blocks <= h->cap_blocks) return JDSP_OK;
     JDSP_HIP(ctx, hipSetDevice(ctx->device));
     JDSP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     free_workspace(h);
@@ -160,10 +157,9 @@ static int reserve2(jdsp_denoise *h, long max_blocks, long mag_blocks)
     if (e == hipSuccess) e = hipMalloc((void **)&h->events, n * sizeof(int));
     if (e == hipSuccess) e = hipMalloc((void **)&h->dbg_energy, n * sizeof(long long));
     if (e == hipSuccess) e = hipMalloc((void **)&h->dbg_zcr, n * sizeof(int));
-    // worst case: every block feeds the noise average; an estimate can latch at most every 10th block.  Magnitude rows
-    // are kept by sharded runs only (the one-GPU path folds them into per-chunk maps in registers, noise_accum_kernel).
-    if (e == hipSuccess && mag_blocks > 0) e = hipMalloc((void **)&h->mag, (size_t)mag_blocks * 1024 * sizeof(float));
-    const size_t n_rows = (n > (size_t)mag_blocks ? n : (size_t)mag_blocks) / 10 + 2;
+    // worst case: every block feeds the noise average; an estimate can latch at most every 10th block.  (No magnitude
+    // rows: noise_accum_kernel folds them into per-chunk maps in registers.)
+    const size_t n_rows = n / 10 + 2;
     if (e == hipSuccess) e = hipMalloc((void **)&h->rows, n_rows * 1024 * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void **)&h->acc.lat_alpha, n_rows * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void **)&h->acc.lat_chunk, n_rows * sizeof(int));
@@ -176,7 +172,6 @@ static int reserve2(jdsp_denoise *h, long max_blocks, long mag_blocks)
         return fail(ctx, e == hipErrorOutOfMemory ? JDSP_ENOMEM : JDSP_EHIP, "jdsp_denoise_reserve", e);
     }
     h->cap_blocks = max_blocks;
-    h->cap_mag = mag_blocks;
     h->cap_rows = (long)n_rows;
     return JDSP_OK;
 }
@@ -361,7 +356,7 @@ int jdsp_denoise_shard_vad_dev(jdsp_denoise *h, const int16_t *pcm_ext_dev, long
     if (b1 > b0 && (!pcm_ext_dev || !flags_own_dev)) return fail(ctx, JDSP_EINVAL, "jdsp_denoise_shard_vad: NULL buffer");
     if ((uintptr_t)pcm_ext_dev & 15u) return fail(ctx, JDSP_EINVAL, "jdsp_denoise_shard_vad: pcm must be 16-byte aligned");
     JDSP_HIP(ctx, hipSetDevice(ctx->device));
-    int rc = reserve2(h, n_total, b1 - b0 + 1);
+    int rc = reserve2(h, n_total);
     if (rc) return rc;
     rc = jdsp_denoise_reset(h);                       // a sharded run is one fresh global stream
     if (rc) return rc;
@@ -383,7 +378,7 @@ int jdsp_denoise_shard_summary_dev(jdsp_denoise *h, const uint8_t *flags_all_dev
     if (jdsp::launch_run_plan(s, flags_all_dev, h->sh_total, h->sh_zero_run, nullptr, 10, h->ver_base, h->snap_mask,
                               h->events, h->ev_n, h->plan) ||
         jdsp::launch_shard_summary(s, h->sh_pcm, h->sh_b1 - h->sh_ext0, h->sh_ext0, h->sh_b0, h->sh_b1, h->events, h->ev_n,
-                                   h->plan, h->ver_base, h->snap_mask, ctx->stft1024_table, h->sh_range, h->mag,
+                                   h->plan, h->ver_base, h->snap_mask, ctx->stft1024_table, h->sh_range, h->acc, h->rows,
                                    summary_dev))
         return fail(ctx, JDSP_EHIP, "shard summary launch", hipGetLastError());
     return JDSP_OK;
@@ -396,8 +391,8 @@ int jdsp_denoise_shard_rows_dev(jdsp_denoise *h, const float *summaries_all_dev,
     if (!summaries_all_dev || !last_dev || world < 1 || rank < 0 || rank >= world)
         return fail(ctx, JDSP_EINVAL, "jdsp_denoise_shard_rows: bad argument");
     JDSP_HIP(ctx, hipSetDevice(ctx->device));
-    if (jdsp::launch_shard_rows(ctx->stream, summaries_all_dev, rank, h->ev_n, h->sh_range, h->mag, h->sh_a_in, h->rows,
-                                last_dev))
+    if (jdsp::launch_shard_rows(ctx->stream, summaries_all_dev, rank, h->sh_b0, h->sh_b1, h->plan, h->sh_range, h->acc,
+                                h->sh_a_in, h->rows, last_dev))
         return fail(ctx, JDSP_EHIP, "shard rows launch", hipGetLastError());
     return JDSP_OK;
 }

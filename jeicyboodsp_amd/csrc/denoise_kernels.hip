@@ -8,10 +8,13 @@
 //                            bit masks: the list of blocks that call EstimateNoiseSpectrum (run
 //                            length >= 2) and, per block, which latched estimate (run length == 10,
 //                            SS:189-193) is current
-//   noise_mag_kernel    A12  |FFT(window * [previous block, block])| for the listed blocks (SS:168-183)
-//   noise_scan_kernel   A12  the running average (SS:182-187), sequential over the list, one bin per thread
-//   denoise_kernel      A8/A9/A10  window -> FFT -> gain -> IFFT -> overlap-add -> (short), fused;
-//                            one wavefront owns K consecutive output blocks and recomputes one halo frame
+//   noise_accum_kernel  A12  |FFT(window * [previous block, block])| of the listed blocks (SS:168-183) folded into one
+//                            affine map of the running average (SS:182-187) per chunk of events, in registers
+//   noise_combine_kernel A12 the chunk maps composed: the average entering every chunk, the latched rows, the state
+//   denoise_run_kernel  A8/A9/A10  window -> FFT -> gain -> IFFT -> overlap-add -> (short), fused; one wavefront
+//                            walks a run of consecutive output blocks and recomputes one halo frame
+// (512-point frames: vad_*<4>, noise_accum512_kernel, denoise512_run_kernel; sharded runs use the same kernels on a
+// rank's range of events.)
 //
 // All of the reference's statics live in DenoiseState (ping-ponged between calls so a launch
 // never reads state it is also writing), which makes batches of any size -- down to the
@@ -334,17 +337,6 @@ __global__ __launch_bounds__(1024) void plan_kernel(const unsigned char *__restr
 }
 
 // ---------------------------------------------------------------------------------------
-// Loads block j of this call as a 16-byte-per-lane image; block -1 is the previous call's
-// last block (state), anything else outside [0, n_blocks) is silence.
-__device__ __forceinline__ u32x4 load_block(const short *__restrict__ pcm, long n_blocks,
-                                            const DenoiseState *__restrict__ st_in, long j, int lane)
-{
-    u32x4 zero = {0u, 0u, 0u, 0u};
-    if (j >= 0 && j < n_blocks) return reinterpret_cast<const u32x4 *>(pcm + j * 512)[lane];
-    if (j == -1) return reinterpret_cast<const u32x4 *>(st_in->prev)[lane];
-    return zero;
-}
-
 // The same block in the transform's own layout: q[r] = the sample pair (2 lane + 128 r, +1), four coalesced
 // dword loads, nothing to re-lay out.
 __device__ __forceinline__ void load_block_pairs(const short *__restrict__ pcm, long n_blocks,
@@ -370,23 +362,6 @@ __device__ __forceinline__ void forward_to_lds(const unsigned int *raw, const Fr
     wave_fft512<false>(v, lds, lane, t.tw);
     store_natural_image(lds, lane, v);
     wave_lds_fence();
-}
-
-// A12, first half: magnitudes of the frames that feed the noise average.
-template <int J>
-__device__ __forceinline__ void mag_store_j(const float2 *lds, int lane, const float2 *wsp, float *dst)
-{
-    const int m = 128 * J + 2 * lane;
-    const float4 zz = *reinterpret_cast<const float4 *>(&lds[m]);
-    float2 zr0, zr1;
-    load_mirror_pair(lds, m, zr0, zr1);
-    float2 lo0, hi0, lo1, hi1;
-    split_fwd<J>(make_float2(zz.x, zz.y), zr0, wsp[0], lo0, hi0);
-    split_fwd<J>(make_float2(zz.z, zz.w), zr1, wsp[1], lo1, hi1);
-    *reinterpret_cast<float2 *>(dst + m) =
-        make_float2(sqrtf(lo0.x * lo0.x + lo0.y * lo0.y), sqrtf(lo1.x * lo1.x + lo1.y * lo1.y));
-    *reinterpret_cast<float2 *>(dst + m + 512) =
-        make_float2(sqrtf(hi0.x * hi0.x + hi0.y * hi0.y), sqrtf(hi1.x * hi1.x + hi1.y * hi1.y));
 }
 
 // ---------------------------------------------------------------------------------------
@@ -422,11 +397,15 @@ __global__ __launch_bounds__(64) void noise_accum_kernel(const short *__restrict
                                                          const int *__restrict__ ver_base,
                                                          const unsigned long long *__restrict__ snap_mask,
                                                          const float2 *__restrict__ table, NoiseAccum acc,
-                                                         float *__restrict__ noise_rows, int latch_run)
+                                                         float *__restrict__ noise_rows, int latch_run,
+                                                         const int *__restrict__ range, long ext0)
 {
+    // range (device, or NULL: every event of the plan) = {first event, one past the last, latches before the first} of a
+    // sharded run; ext0 = global index of the first block `pcm` holds (sharded runs; st_in is then NULL and never needed)
     __shared__ __attribute__((aligned(16))) float2 lds[kWaveLdsComplex];
     const int lane = threadIdx.x;
-    const int n_events = plan->n_events;
+    const int e_base = range ? range[0] : 0, row_off = range ? range[2] : 0;
+    const int n_events = range ? range[1] - range[0] : plan->n_events;
     const ChunkGeom cg = chunk_geom(n_events, (int)gridDim.x);
     const int chunk = blockIdx.x;
     if (chunk >= cg.n_chunks) return;
@@ -440,8 +419,8 @@ __global__ __launch_bounds__(64) void noise_accum_kernel(const short *__restrict
 #pragma unroll
     for (int d = 0; d < 8; d++) blo[d] = bhi[d] = 0.0f;
     for (int e = e0; e < e1; e++) {
-        const long j = events[e];
-        const int n = ev_n[e];
+        const long jg = events[e_base + e], j = jg - ext0;
+        const int n = ev_n[e_base + e];
         unsigned int prev[4], cur[4];
         load_block_pairs(pcm, n_blocks, st_in, j - 1, lane, prev);   // rgssKeepBuffer (SS:165-170)
         load_block_pairs(pcm, n_blocks, st_in, j, lane, cur);
@@ -466,7 +445,7 @@ __global__ __launch_bounds__(64) void noise_accum_kernel(const short *__restrict
         }
         alpha *= h;
         if (n == latch_run) {                                    // SS:189-193
-            const int row = version_of(ver_base, snap_mask, j);
+            const int row = version_of(ver_base, snap_mask, jg) - row_off;
             float *dst = noise_rows + (size_t)row * 1024 + lane;
 #pragma unroll
             for (int d = 0; d < 8; d++) { dst[64 * d] = blo[d]; dst[64 * d + 512] = bhi[d]; }
@@ -485,15 +464,22 @@ __global__ __launch_bounds__(64) void noise_accum_kernel(const short *__restrict
 #define JDSP_COMBINE_BINS 16
 #endif
 constexpr int kCombineBins = JDSP_COMBINE_BINS, kCombineGroups = 1024 / JDSP_COMBINE_BINS;
+// Sharded runs (range != NULL: {first event, one past the last, latches before, latches inside} of this rank): the
+// average starts from a_in (NULL: zero), summary (or NULL) receives the rank's composed map {alpha, beta[1024]}, last
+// (or NULL) {number of latches, the last latched row}; complete_rows = 0 leaves the latched rows' partial maps alone
+// (the first of a rank's two passes: its a_in is not known yet).
 __global__ __launch_bounds__(1024) void noise_combine_kernel(const DenoisePlan *__restrict__ plan,
                                                              const DenoiseState *__restrict__ st_in, DenoiseState *st_out,
-                                                             NoiseAccum acc, float *__restrict__ noise_rows, int accum_grid)
+                                                             NoiseAccum acc, float *__restrict__ noise_rows, int accum_grid,
+                                                             const int *__restrict__ range, const float *__restrict__ a_in,
+                                                             float *__restrict__ summary, float *__restrict__ last,
+                                                             int complete_rows)
 {
     __shared__ float ga[kCombineGroups][kCombineBins], gb[kCombineGroups][kCombineBins];
     const int bl = threadIdx.x % kCombineBins, g = threadIdx.x / kCombineBins;
     const int bin = blockIdx.x * kCombineBins + bl;
-    const int n_snap = plan->n_snap;
-    const ChunkGeom cg = chunk_geom(plan->n_events, accum_grid);
+    const int n_snap = range ? range[3] : plan->n_snap;
+    const ChunkGeom cg = chunk_geom(range ? range[1] - range[0] : plan->n_events, accum_grid);
     const int per_group = (cg.n_chunks + kCombineGroups - 1) / kCombineGroups;
     const int c0 = g * per_group < cg.n_chunks ? g * per_group : cg.n_chunks;
     const int c1 = c0 + per_group < cg.n_chunks ? c0 + per_group : cg.n_chunks;
@@ -519,7 +505,12 @@ __global__ __launch_bounds__(1024) void noise_combine_kernel(const DenoisePlan *
         gb[g][bl] = b;
     }
     __syncthreads();
-    float A = st_in->avg[bin];
+    if (summary && blockIdx.x == 0 && threadIdx.x == 0) {
+        float p = 1.0f;
+        for (int q = 0; q < kCombineGroups; q++) p *= ga[q][0];
+        summary[0] = p;                                          // alpha = 2^-(number of halvings)
+    }
+    float A = a_in ? a_in[bin] : (st_in ? st_in->avg[bin] : 0.0f);
     for (int q = 0; q < g; q++) A = ga[q][bl] * A + gb[q][bl];   // the average entering this group
     for (int cb = c0; cb < c1; cb += kBatch) {
         float al[kBatch], be[kBatch];
@@ -536,15 +527,25 @@ __global__ __launch_bounds__(1024) void noise_combine_kernel(const DenoisePlan *
                 A = al[u] * A + be[u];
             }
     }
-    if (g == kCombineGroups - 1) st_out->avg[bin] = A;           // groups past the last chunk are identities
-    if (g == 0) noise_rows[bin] = st_in->noise[bin];             // row 0: the estimate carried in
-    __syncthreads();                                             // a_start is read back by other threads of this workgroup
-    for (int r = 1 + g; r <= n_snap; r += kCombineGroups) {
-        float *row = noise_rows + (size_t)r * 1024 + bin;
-        *row = acc.lat_alpha[r] * acc.a_start[(size_t)acc.lat_chunk[r] * 1024 + bin] + *row;
+    if (g == kCombineGroups - 1) {                               // groups past the last chunk are identities
+        if (st_out) st_out->avg[bin] = A;
+        if (summary) summary[1 + bin] = A;
     }
+    if (g == 0 && st_in) noise_rows[bin] = st_in->noise[bin];    // row 0: the estimate carried in
+    __syncthreads();                                             // a_start is read back by other threads of this workgroup
+    if (complete_rows)
+        for (int r = 1 + g; r <= n_snap; r += kCombineGroups) {
+            float *row = noise_rows + (size_t)r * 1024 + bin;
+            *row = acc.lat_alpha[r] * acc.a_start[(size_t)acc.lat_chunk[r] * 1024 + bin] + *row;
+        }
     __syncthreads();
-    if (g == 0) st_out->noise[bin] = n_snap > 0 ? noise_rows[(size_t)n_snap * 1024 + bin] : st_in->noise[bin];
+    if (g == 0) {
+        if (st_out) st_out->noise[bin] = n_snap > 0 ? noise_rows[(size_t)n_snap * 1024 + bin] : st_in->noise[bin];
+        if (last) {
+            last[1 + bin] = n_snap > 0 ? noise_rows[(size_t)n_snap * 1024 + bin] : 0.0f;
+            if (bin == 0) last[0] = (float)n_snap;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1029,69 +1030,7 @@ __global__ void event_range_kernel(const int *__restrict__ events, const Denoise
     while (lo < hi) { const int mid = (lo + hi) >> 1; if (events[mid] < b1) lo = mid + 1; else hi = mid; }
     range[1] = lo;
     range[2] = b0 > 0 ? version_of(ver_base, snap_mask, b0 - 1) : 0;     // latches before the shard = row offset
-}
-
-__global__ __launch_bounds__(64) void noise_mag_range_kernel(const short *__restrict__ pcm_ext, long n_ext, long ext0,
-                                                             const int *__restrict__ events,
-                                                             const int *__restrict__ range,
-                                                             const float2 *__restrict__ table, float *__restrict__ mag)
-{
-    __shared__ __attribute__((aligned(16))) float2 lds[kWaveLdsComplex];
-    __shared__ __attribute__((aligned(16))) unsigned int stage[256];
-    const int lane = threadIdx.x;
-    const int e0 = range[0], e1 = range[1];
-    if (e0 + (int)blockIdx.x >= e1) return;
-    FrameTables t;
-    load_frame_tables(t, table, lane);
-    for (int e = e0 + blockIdx.x; e < e1; e += gridDim.x) {
-        const long j = events[e] - ext0;                                  // local block index, >= 1
-        const u32x4 h0 = load_block(pcm_ext, n_ext, nullptr, j - 1 >= 0 ? j - 1 : -2, lane);
-        const u32x4 h1 = load_block(pcm_ext, n_ext, nullptr, j, lane);
-        unsigned int raw[8];
-        relayout_half(stage, lane, h0, raw);
-        relayout_half(stage, lane, h1, raw + 4);
-        forward_to_lds(raw, t, lds, lane);
-        float *dst = mag + (size_t)(e - e0) * 1024;
-        mag_store_j<0>(lds, lane, t.wsp, dst);
-        mag_store_j<1>(lds, lane, t.wsp, dst);
-        mag_store_j<2>(lds, lane, t.wsp, dst);
-        mag_store_j<3>(lds, lane, t.wsp, dst);
-        wave_lds_fence();
-    }
-}
-
-// One pass over this rank's events from the average `a_in` (NULL: zero).  summary (may be NULL):
-// [0] = alpha = 2^-(number of halvings), [1..1024] = the average after the last event.
-// rows (may be NULL): row k >= 1 = the k-th estimate latched inside the shard.
-// last (may be NULL): [0] = number of latches, [1..1024] = the last one.
-__global__ __launch_bounds__(256) void noise_scan_range_kernel(const float *__restrict__ mag, const int *__restrict__ ev_n,
-                                                               const int *__restrict__ range,
-                                                               const float *__restrict__ a_in, float *__restrict__ summary,
-                                                               float *__restrict__ rows, float *__restrict__ last)
-{
-    const int bin = blockIdx.x * blockDim.x + threadIdx.x;
-    const int e0 = range[0], e1 = range[1];
-    float avg = a_in ? a_in[bin] : 0.f;
-    float alpha = 1.f, latched = 0.f;
-    int row = 0;
-    for (int e = e0; e < e1; e++) {
-        const int n = ev_n[e];
-        avg += mag[(size_t)(e - e0) * 1024 + bin];
-        if (n >= 3) { avg *= 0.5f; alpha *= 0.5f; }
-        if (n == 10) {
-            row++;
-            latched = avg;
-            if (rows) rows[(size_t)row * 1024 + bin] = avg;
-        }
-    }
-    if (summary) {
-        summary[1 + bin] = avg;
-        if (bin == 0) summary[0] = alpha;
-    }
-    if (last) {
-        last[1 + bin] = latched;
-        if (bin == 0) last[0] = (float)row;
-    }
+    range[3] = (b1 > b0 ? version_of(ver_base, snap_mask, b1 - 1) : range[2]) - range[2];   // latches inside it
 }
 
 // A entering rank `rank` = the pairs of the ranks before it applied in order.
@@ -1114,27 +1053,33 @@ __global__ __launch_bounds__(256) void select_row0_kernel(const float *__restric
     rows[bin] = v;
 }
 
+// A rank's events through the chunked average (noise_accum_kernel / noise_combine_kernel) in two passes: the first
+// leaves the rank's composed map in `summary` (and every latched row as its partial map), the second -- once the
+// maps of the ranks before it are known -- completes the rows from the average this rank starts from.
+static int shard_accum_grid(long own) { return own < kNoiseChunks ? (int)(own > 0 ? own : 1) : kNoiseChunks; }
+
 int launch_shard_summary(hipStream_t s, const short *pcm_ext, long n_ext, long ext0, long b0, long b1,
                          const int *events, const int *ev_n, const DenoisePlan *plan, const int *ver_base,
-                         const unsigned long long *snap_mask, const float2 *table, int *range, float *mag,
-                         float *summary)
+                         const unsigned long long *snap_mask, const float2 *table, int *range, const NoiseAccum &acc,
+                         float *rows, float *summary)
 {
     hipLaunchKernelGGL(event_range_kernel, dim3(1), dim3(64), 0, s, events, plan, ver_base, snap_mask, b0, b1, range);
-    const long own = b1 - b0;
-    const long grid = own < 4096 ? (own > 0 ? own : 1) : 4096;
-    hipLaunchKernelGGL(noise_mag_range_kernel, dim3((unsigned)grid), dim3(64), 0, s, pcm_ext, n_ext, ext0, events, range,
-                       table, mag);
-    hipLaunchKernelGGL(noise_scan_range_kernel, dim3(4), dim3(256), 0, s, mag, ev_n, range, (const float *)nullptr,
-                       summary, (float *)nullptr, (float *)nullptr);
+    const int grid = shard_accum_grid(b1 - b0);
+    hipLaunchKernelGGL(noise_accum_kernel, dim3((unsigned)grid), dim3(64), 0, s, pcm_ext, n_ext, (const DenoiseState *)nullptr,
+                       events, ev_n, plan, ver_base, snap_mask, table, acc, rows, 10, (const int *)range, ext0);
+    hipLaunchKernelGGL(noise_combine_kernel, dim3(1024 / kCombineBins), dim3(1024), 0, s, plan, (const DenoiseState *)nullptr,
+                       (DenoiseState *)nullptr, acc, rows, grid, (const int *)range, (const float *)nullptr, summary,
+                       (float *)nullptr, 0);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
-int launch_shard_rows(hipStream_t s, const float *summaries_all, int rank, const int *ev_n, const int *range,
-                      const float *mag, float *a_in, float *rows, float *last)
+int launch_shard_rows(hipStream_t s, const float *summaries_all, int rank, long b0, long b1, const DenoisePlan *plan,
+                      const int *range, const NoiseAccum &acc, float *a_in, float *rows, float *last)
 {
     hipLaunchKernelGGL(fold_summaries_kernel, dim3(4), dim3(256), 0, s, summaries_all, rank, a_in);
-    hipLaunchKernelGGL(noise_scan_range_kernel, dim3(4), dim3(256), 0, s, mag, ev_n, range, (const float *)a_in,
-                       (float *)nullptr, rows, last);
+    hipLaunchKernelGGL(noise_combine_kernel, dim3(1024 / kCombineBins), dim3(1024), 0, s, plan, (const DenoiseState *)nullptr,
+                       (DenoiseState *)nullptr, acc, rows, shard_accum_grid(b1 - b0), range, (const float *)a_in,
+                       (float *)nullptr, last, 1);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
@@ -1197,8 +1142,9 @@ int launch_noise_estimate(hipStream_t s, const short *pcm, long n_blocks, const 
     const int grid = n_blocks < kNoiseChunks ? (int)(n_blocks > 0 ? n_blocks : 1) : kNoiseChunks;
     if (n_blocks > 0)
         hipLaunchKernelGGL(noise_accum_kernel, dim3((unsigned)grid), dim3(64), 0, s, pcm, n_blocks, st_in, events, ev_n, plan,
-                           ver_base, snap_mask, table, acc, noise_rows, 10);
-    hipLaunchKernelGGL(noise_combine_kernel, dim3(1024 / kCombineBins), dim3(1024), 0, s, plan, st_in, st_out, acc, noise_rows, grid);
+                           ver_base, snap_mask, table, acc, noise_rows, 10, (const int *)nullptr, 0L);
+    hipLaunchKernelGGL(noise_combine_kernel, dim3(1024 / kCombineBins), dim3(1024), 0, s, plan, st_in, st_out, acc, noise_rows, grid,
+                       (const int *)nullptr, (const float *)nullptr, (float *)nullptr, (float *)nullptr, 1);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
@@ -1712,7 +1658,8 @@ int launch_noise_estimate512(hipStream_t s, const short *pcm, long n_blocks, con
         hipLaunchKernelGGL(noise_accum512_kernel, dim3((unsigned)grid), dim3(64), 0, s, pcm, n_blocks, st_in, events, ev_n,
                            plan, ver_base, snap_mask, table, win512, acc, noise_rows, 10);
     // bins 0..511 only (rows keep the 1024-float pitch of the 1024-point path)
-    hipLaunchKernelGGL(noise_combine_kernel, dim3(512 / kCombineBins), dim3(1024), 0, s, plan, st_in, st_out, acc, noise_rows, grid);
+    hipLaunchKernelGGL(noise_combine_kernel, dim3(512 / kCombineBins), dim3(1024), 0, s, plan, st_in, st_out, acc, noise_rows, grid,
+                       (const int *)nullptr, (const float *)nullptr, (float *)nullptr, (float *)nullptr, 1);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

@@ -167,10 +167,10 @@ int launch_denoise(hipStream_t s, int mode, int k_opt, int n_cu, const short *pc
                    float *precast, const DenoiseShard *shard = nullptr);
 int launch_shard_summary(hipStream_t s, const short *pcm_ext, long n_ext, long ext0, long b0, long b1,
                          const int *events, const int *ev_n, const DenoisePlan *plan, const int *ver_base,
-                         const unsigned long long *snap_mask, const float2 *table, int *range, float *mag,
-                         float *summary);
-int launch_shard_rows(hipStream_t s, const float *summaries_all, int rank, const int *ev_n, const int *range,
-                      const float *mag, float *a_in, float *rows, float *last);
+                         const unsigned long long *snap_mask, const float2 *table, int *range, const NoiseAccum &acc,
+                         float *rows, float *summary);
+int launch_shard_rows(hipStream_t s, const float *summaries_all, int rank, long b0, long b1, const DenoisePlan *plan,
+                      const int *range, const NoiseAccum &acc, float *a_in, float *rows, float *last);
 int launch_shard_row0(hipStream_t s, const float *last_all, int rank, float *rows);
 int ensure_stft1024_table(jdsp_ctx *ctx);
 int ensure_vad_window(jdsp_ctx *ctx);
@@ -254,14 +254,13 @@ struct jdsp_denoise {
     int cur = 0;                          // st[cur] is the state the next call reads
     double *w_hi = nullptr;               // second half of the FP64 Hamming window (VAD)
     long cap_blocks = 0;                  // workspace capacity (plan arrays)
-    long cap_mag = 0;                     // workspace capacity (magnitude rows)
     unsigned char *flags = nullptr;
     int *ev_n = nullptr, *ver_base = nullptr, *events = nullptr;
     unsigned long long *snap_mask = nullptr;
     long long *dbg_energy = nullptr;
     int *dbg_zcr = nullptr;
     jdsp::DenoisePlan *plan = nullptr;
-    float *mag = nullptr, *rows = nullptr;   // mag: sharded runs only (magnitude rows of this GPU's events)
+    float *rows = nullptr;                // [cap_rows][1024] latched estimates of the call (row 0: the one carried in)
     long cap_rows = 0;                    // rows of `rows` / entries of acc.lat_*
     jdsp::NoiseAccum acc = {nullptr, nullptr, nullptr, nullptr, nullptr};
     long last_blocks = 0;

@@ -85,3 +85,15 @@ def test_denoise_sharded_driver_world1(eng, oracle):
     torch.cuda.synchronize()
     assert np.abs(out.cpu().numpy().astype(np.int32) - want.astype(np.int32)).max() <= 1
     d.close()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_pause_heavy_stream(eng, oracle, world):
+    """Thousands of noise-estimation events per rank: the ranks' events go through the same chunked average as the
+    one-GPU path (several events per chunk, latches in the middle of chunks), then the ranks' maps are folded."""
+    n_blocks = 13000
+    pcm = speechlike(23, n_blocks, [40, 3, 25, 1, 90, 2, 11, 5])
+    want, _ = oracle.denoise_stream(0, pcm)
+    got = run_sharded(eng, 0, pcm, world)
+    assert got.shape == want.shape
+    assert np.abs(got.astype(np.int32) - want.astype(np.int32)).max() <= 1
