@@ -147,6 +147,9 @@ __global__ __launch_bounds__(64) void fastconv1024_kernel(ConvStream s, long n_o
 #ifndef JDSP_CONV1024_PAIRS
 #define JDSP_CONV1024_PAIRS 1
 #endif
+#ifndef JDSP_CONV_ABLATE
+#define JDSP_CONV_ABLATE 0          // timing-only ablations of fastconv1024_pairs_kernel (tools/build_variant.sh): wrong results
+#endif
 #ifndef JDSP_CONV1024_GRID
 #define JDSP_CONV1024_GRID (1024 * JDSP_CONV1024_MINWAVES)
 #endif
@@ -282,12 +285,22 @@ __global__ __launch_bounds__(64, JDSP_CONV1024_MINWAVES) void fastconv1024_pairs
                 else y[d] = presplit_inv_reg(yl, yh, pw.w[d]);
             }
             pair_return_lds(ret, lds, lane, y);
+#if !(JDSP_CONV_ABLATE & 1)                                            /* 1, timing-only: no inverse transforms */
             wave_fft512<true>(y, lds, lane, tw);
+#endif
             wave_lds_fence();
             short *obase = out + (size_t)f * plane + e * block - n0;         // obase[n] = where sample n of the segment goes
             const int odd = (int)((reinterpret_cast<uintptr_t>(obase) >> 1) & 1);  // wave-uniform: which pairing is dword-aligned
             unsigned int *p32 = reinterpret_cast<unsigned int *>(obase + 2 * lane + odd);
             float *pc = precast ? precast + (size_t)f * plane + e * block - n0 : nullptr;
+#if JDSP_CONV_ABLATE & 2                                               /* 2, timing-only: aligned stores only */
+            if (true) {
+#pragma unroll
+                for (int d = 2; d < 8; d++)
+                    __builtin_nontemporal_store(cast_i16_bits(y[d].x) | (cast_i16_bits(y[d].y) << 16),
+                                                reinterpret_cast<unsigned int *>(out + (size_t)f * plane + e * block + odd) + lane + 64 * (d - 2));
+            } else
+#endif
             if (!odd) {
 #pragma unroll
                 for (int d = 0; d < 8; d++) {
