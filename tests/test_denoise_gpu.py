@@ -401,3 +401,28 @@ def _runs_of_zero(flags):
     if n:
         runs.append(n)
     return runs
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_streams_and_call_cuts(eng, oracle, seed):
+    """Seeded random stream lengths, pause patterns and call boundaries, both frame sizes and modes: the plan's event
+    list, the chunked average, the run kernels' halo logic and the state hand-over all at once, against the oracle."""
+    rng = np.random.default_rng(1000 + seed)
+    block = 512 if seed % 2 == 0 else 256
+    n_fft = 2 * block
+    mode = (seed // 2) % 2
+    n_blocks = int(rng.integers(1, 900))
+    pattern = [int(v) for v in rng.integers(1, 40, size=int(rng.integers(2, 9)))]
+    gen = speechlike if block == 512 else speechlike256
+    pcm = gen(2000 + seed, n_blocks, pattern=pattern)
+    o_out, o_pre, flags, noises, ver = oracle.denoise_trace(mode, pcm, block=block)
+    d = eng.denoiser(mode, n_fft, block)
+    cuts = sorted(set(int(v) for v in rng.integers(0, n_blocks + 1, size=int(rng.integers(0, 6)))) | {0, n_blocks})
+    outs, pres = [], []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        o, p = d.process(pcm[a * block:b * block], want_precast=True)
+        outs.append(o)
+        pres.append(p)
+    check_stream(np.concatenate(outs), np.concatenate(pres), o_out, o_pre)
+    assert np.abs(d.noise() - noises[-1]).max() <= TOL * max(noises[-1].max(), 1.0)
+    d.close()
