@@ -570,7 +570,7 @@ __device__ __forceinline__ float2 apply_gain(float2 x, float n)
         return make_float2(x.x * g, x.y * g);
 #endif
     } else {
-        float r = (n * n) * __frcp_rn(p);                    // 0 * inf = NaN keeps the reference's 0/0
+        float r = (n * n) * __builtin_amdgcn_rcpf(p);                    // 0 * inf = NaN keeps the reference's 0/0
         if (r >= 1.0f) r = 1.0f;
         const float g = 1.0f - r;
         return make_float2(x.x * g, x.y * g);
@@ -743,7 +743,8 @@ __device__ __forceinline__ float2 apply_gain_scaled(float2 x, float n)
         const bool zero = p == 0.0f;
         return make_float2(zero ? -n : x.x * g, zero ? 0.0f : x.y * g);
     } else {
-        float r = (n * n) * __frcp_rn(p);                    // 0 * inf = NaN keeps the reference's 0/0
+        // v_rcp_f32 (1 ulp; __frcp_rn() expands to the IEEE division sequence, a dozen instructions per bin)
+        float r = (n * n) * __builtin_amdgcn_rcpf(p);                    // 0 * inf = NaN keeps the reference's 0/0
         if (r >= 1.0f) r = 1.0f;
         const float g = c - c * r;
         return make_float2(x.x * g, x.y * g);
