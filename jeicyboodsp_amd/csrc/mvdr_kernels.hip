@@ -43,6 +43,25 @@ __device__ __forceinline__ void spectrum_of(float2 (&v)[8], float2 *lds, int lan
     wave_lds_fence();
 }
 
+// sum over the wave, valid in lane 63 (quad swaps, row mirrors, row broadcasts: five DPP steps on both halves of the double)
+__device__ __forceinline__ double wave_sum_f64(double v)
+{
+#define JDSP_DPP_ADD64(CTRL, ROWS)                                                                             \
+    {                                                                                                          \
+        const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROWS, 0xf, true);               \
+        const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROWS, 0xf, true);               \
+        v += __hiloint2double(hi, lo);                                                                         \
+    }
+    JDSP_DPP_ADD64(0xB1, 0xf)      // quad_perm [1,0,3,2]
+    JDSP_DPP_ADD64(0x4E, 0xf)      // quad_perm [2,3,0,1]
+    JDSP_DPP_ADD64(0x141, 0xf)     // row_half_mirror: sums of 8
+    JDSP_DPP_ADD64(0x140, 0xf)     // row_mirror: sums of 16
+    JDSP_DPP_ADD64(0x142, 0xa)     // row_bcast15 into rows 1 and 3
+    JDSP_DPP_ADD64(0x143, 0xc)     // row_bcast31 into rows 2 and 3
+#undef JDSP_DPP_ADD64
+    return v;
+}
+
 // :244-270 -- frame = [block j-1, block j] of each channel, no window
 __global__ __launch_bounds__(64) void mvdr_corr_kernel(const short *__restrict__ left, const short *__restrict__ right,
                                                        long n_blocks, const MvdrState *__restrict__ st_in,
@@ -87,12 +106,10 @@ __global__ __launch_bounds__(64) void mvdr_corr_kernel(const short *__restrict__
                 s11 += (double)(R.x * R.x + R.y * R.y);                 // :267
             }
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            s00 += __shfl_xor(s00, o); s01 += __shfl_xor(s01, o);
-            s10 += __shfl_xor(s10, o); s11 += __shfl_xor(s11, o);
-        }
-        if (lane == 0) {
+        // wave sums by DPP moves (lane 63 ends up with the total): a __shfl_xor tree is 48 ds_bpermute here, 8.9 issue
+        // slots each -- and an all-quiet stream runs this once per block
+        s00 = wave_sum_f64(s00); s01 = wave_sum_f64(s01); s10 = wave_sum_f64(s10); s11 = wave_sum_f64(s11);
+        if (lane == 63) {
             double *d = delta + (size_t)(e - e_lo) * 4;
             d[0] = s00 / 1024.0; d[1] = s01 / 1024.0; d[2] = s10 / 1024.0; d[3] = s11 / 1024.0;
         }

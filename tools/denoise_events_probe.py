@@ -57,7 +57,9 @@ def main():
     rng = np.random.default_rng(5)
     B = 65536
     if a.mvdr:
-        for pause_frac, mean_run in ((0.0, 0), (0.1, 20), (0.5, 40), (1.0, 1 << 30)):
+        for i, (pause_frac, mean_run) in enumerate(((0.0, 0), (0.1, 20), (0.5, 40), (1.0, 1 << 30))):
+            if a.case >= 0 and i != a.case:
+                continue
             l, n_quiet = stream(rng, B, 512, pause_frac, mean_run)
             r = np.roll(l, 3)
             tl, tr = torch.from_numpy(l).cuda(), torch.from_numpy(r).cuda()
@@ -67,6 +69,8 @@ def main():
             print(json.dumps({"chain": "mvdr_2mic", "blocks": B, "pause_frac": pause_frac, "quiet_blocks": n_quiet,
                               "us_per_call": round(ms * 1e3, 1)}), flush=True)
             mv.close()
+        if a.case >= 0:
+            return
         nb = 16384
         for pause_frac, mean_run in ((0.0, 0), (0.01, 20), (0.1, 20)):
             x, n_quiet = stream(rng, nb, 512, pause_frac, mean_run)
