@@ -202,21 +202,23 @@ int ensure_stft1024_table_rect(jdsp_ctx *ctx);
 int launch_mvdr(hipStream_t s, const short *left, const short *right, long n_blocks, long calls_before,
                 const MvdrState *st_in, MvdrState *st_out, const int *events, const DenoisePlan *plan,
                 const int *ver_base, const unsigned long long *snap_mask, double *delta, double *rver,
-                const double2 *steer, const float2 *table, short *out, float *precast, float4 *wtab);
+                const double2 *steer, const float2 *table, short *out, float *precast, float4 *wtab,
+                double *tile_sums);
 int launch_mvdr_corr_total(hipStream_t s, const short *left, const short *right, long n_blocks, const MvdrState *st_in,
-                           const int *events, const DenoisePlan *plan, const float2 *table, double *delta, double *total);
+                           const int *events, const DenoisePlan *plan, const float2 *table, double *delta, double *total,
+                           double *tile_sums);
 int launch_mvdr_apply(hipStream_t s, const short *left, const short *right, long n_blocks, long calls_before,
                       const MvdrState *st_in, MvdrState *st_out, const int *ver_base, const unsigned long long *snap_mask,
                       const double *rver, const double2 *steer, const float2 *table, short *out, float *precast);
 int launch_mvdr_shard_summary(hipStream_t s, const short *left_ext, const short *right_ext, long n_ext, long ext0,
                               long b0, long b1, const MvdrState *zero_state, const int *events,
                               const DenoisePlan *plan, const int *ver_base, const unsigned long long *snap_mask,
-                              const float2 *table, int *range, double *delta, double *total);
+                              const float2 *table, int *range, double *delta, double *total, double *tile_sums);
 int launch_mvdr_shard_finish(hipStream_t s, const short *left_ext, const short *right_ext, long n_ext, long ext0,
                              long b0, long b1, const MvdrState *zero_state, MvdrState *scratch_state,
                              const DenoisePlan *plan, const int *ver_base, const unsigned long long *snap_mask,
                              const int *range, const double *delta, const double *sums_all, int rank, double *rver,
-                             const double2 *steer, const float2 *table, short *out, float *precast);
+                             const double2 *steer, const float2 *table, short *out, float *precast, double *tile_sums);
 // mvdrn_kernels.hip
 int launch_mvdrn(hipStream_t s, const short *pcm, long chan_stride, int n_mics, long n_blocks, long calls_before,
                  const short *prev_in, short *prev_out, const int *events, const DenoisePlan *plan, const int *ver_base,
@@ -338,6 +340,7 @@ struct jdsp_mvdr {
     int *events = nullptr, *ev_n = nullptr, *ver_base = nullptr;
     unsigned long long *snap_mask = nullptr;
     double *delta = nullptr, *rver = nullptr;
+    double *tile_sums = nullptr;          // [cap_blocks / 1024 + 1][4] sums of the prefix pass's tiles of 1024 events
     float4 *wtab = nullptr;               // [kMvdrTableVersions][1024] per-version weights (mvdr_weights_kernel)
     // sharded (multi-GPU) run in progress
     long sh_ext0 = 0, sh_b0 = 0, sh_b1 = 0, sh_total = 0;

@@ -5,13 +5,13 @@ using jdsp::fail;
 
 static void mvdr_free_ws(jdsp_mvdr *h)
 {
-    void *p[] = {h->flags, h->events, h->ev_n, h->ver_base, h->snap_mask, h->delta, h->rver};
+    void *p[] = {h->flags, h->events, h->ev_n, h->ver_base, h->snap_mask, h->delta, h->rver, h->tile_sums};
     for (void *q : p)
         if (q) (void)hipFree(q);
     h->flags = nullptr;
     h->events = h->ev_n = h->ver_base = nullptr;
     h->snap_mask = nullptr;
-    h->delta = h->rver = nullptr;
+    h->delta = h->rver = h->tile_sums = nullptr;
     h->cap_blocks = 0;
 }
 
@@ -107,6 +107,7 @@ static int mvdr_reserve(jdsp_mvdr *h, long n_blocks)
     if (e == hipSuccess) e = hipMalloc((void **)&h->snap_mask, (n / 64 + 1) * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMalloc((void **)&h->delta, n * 4 * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void **)&h->rver, (n + 1) * 4 * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void **)&h->tile_sums, (n / 1024 + 1) * 4 * sizeof(double));
     if (e != hipSuccess) {
         mvdr_free_ws(h);
         return fail(ctx, JDSP_ENOMEM, "jdsp_mvdr: workspace", e);
@@ -137,7 +138,7 @@ int jdsp_mvdr_process_dev(jdsp_mvdr *h, const int16_t *left_dev, const int16_t *
         jdsp::launch_run_plan(s, h->flags, n_blocks, &st_in->run_len, &st_out->run_len, 0, h->ver_base, h->snap_mask,
                               h->events, h->ev_n, h->plan) ||
         jdsp::launch_mvdr(s, left_dev, right_dev, n_blocks, h->calls, st_in, st_out, h->events, h->plan, h->ver_base,
-                          h->snap_mask, h->delta, h->rver, h->steer, ctx->stft1024_table, out_dev, precast_dev, h->wtab))
+                          h->snap_mask, h->delta, h->rver, h->steer, ctx->stft1024_table, out_dev, precast_dev, h->wtab, h->tile_sums))
         return fail(ctx, JDSP_EHIP, "mvdr launch", hipGetLastError());
     h->cur ^= 1;
     h->calls += n_blocks;
@@ -214,7 +215,7 @@ int jdsp_mvdr_shard_summary_dev(jdsp_mvdr *h, const uint8_t *flags_all_dev, doub
                               h->ev_n, h->plan) ||
         jdsp::launch_mvdr_shard_summary(s, h->sh_left, h->sh_right, h->sh_b1 - h->sh_ext0, h->sh_ext0, h->sh_b0, h->sh_b1,
                                         h->st[h->cur], h->events, h->plan, h->ver_base, h->snap_mask, ctx->stft1024_table,
-                                        h->sh_range, h->delta, sum4_dev))
+                                        h->sh_range, h->delta, sum4_dev, h->tile_sums))
         return fail(ctx, JDSP_EHIP, "mvdr shard summary launch", hipGetLastError());
     return JDSP_OK;
 }
@@ -239,7 +240,7 @@ int jdsp_mvdr_shard_finish_dev(jdsp_mvdr *h, const double *sums_all_dev, int wor
     if (jdsp::launch_mvdr_shard_finish(ctx->stream, h->sh_left, h->sh_right, h->sh_b1 - h->sh_ext0, h->sh_ext0, h->sh_b0,
                                        h->sh_b1, h->st[h->cur], h->st[h->cur ^ 1], h->plan, h->ver_base, h->snap_mask,
                                        h->sh_range, h->delta, sums_all_dev, rank, h->rver, h->steer, ctx->stft1024_table,
-                                       out_dev, precast_dev))
+                                       out_dev, precast_dev, h->tile_sums))
         return fail(ctx, JDSP_EHIP, "mvdr shard finish launch", hipGetLastError());
     return JDSP_OK;
 }
@@ -274,7 +275,7 @@ int jdsp_mvdr_estimate_corr(jdsp_mvdr *h, const int16_t *left_frames_host, const
     if (e != hipSuccess) rc = fail(ctx, JDSP_EHIP, "jdsp_mvdr_estimate_corr: staging", e);
     double tot[4] = {0, 0, 0, 0};
     if (!rc && jdsp::launch_mvdr_corr_total(s, d_l, d_r, 2 * n_frames, h->st[h->cur], h->events, h->plan, ctx->stft1024_table,
-                                            h->delta, d_tot))
+                                            h->delta, d_tot, h->tile_sums))
         rc = fail(ctx, JDSP_EHIP, "mvdr corr launch", hipGetLastError());
     if (!rc && (e = hipMemcpyAsync(tot, d_tot, sizeof(tot), hipMemcpyDeviceToHost, s)) != hipSuccess)
         rc = fail(ctx, JDSP_EHIP, "jdsp_mvdr_estimate_corr: D2H", e);

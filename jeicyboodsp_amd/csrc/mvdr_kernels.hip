@@ -118,21 +118,25 @@ __global__ __launch_bounds__(64) void mvdr_corr_kernel(const short *__restrict__
 
 // R after event e: rver[e+1] = rver[e] + delta[e]; rver[0] = the matrix carried in (the state's,
 // or for a sharded run the sum of the earlier ranks' totals).  total (may be NULL) = sum of delta.
-// One workgroup of 1024 threads, each owning a run of consecutive events: local sums, a scan of the 1024 sums, then
-// the run again with its base -- a stream that is half pauses has tens of thousands of events per call, and four threads
-// walking them one by one took a third of a microsecond per event.  (FP64 sums, so the grouping moves nothing above 1e-16.)
+// Two launches over tiles of 1024 events: an LDS scan inside each tile (coalesced 32-byte rows, the tile's sum to
+// tile_sums), then each tile's base = matrix carried in + the sums of the tiles before it.  A stream that is half pauses
+// has tens of thousands of events per call: one workgroup walking them took 218 us for 65,536 (every thread's run of
+// events a cache line apart from its neighbour's).  (FP64 sums, so the grouping moves nothing above 1e-16.)
+constexpr int kPrefixGrid = 64;
+
 __global__ __launch_bounds__(1024) void mvdr_prefix_kernel(const double *__restrict__ delta,
                                                            const DenoisePlan *__restrict__ plan,
                                                            const int *__restrict__ range, const double *__restrict__ r_in,
                                                            const double *__restrict__ sums_all, int rank, MvdrState *st_out,
-                                                           double *__restrict__ rver, double *__restrict__ total)
+                                                           double *__restrict__ rver, double *__restrict__ total,
+                                                           double *__restrict__ tile_sums)
 {
     __shared__ double part[2][4][1024];
     const int t = threadIdx.x;
     const int n = range ? range[1] - range[0] : plan->n_events;
     if (n <= 64) {
         // a handful of events (a loud stream): four threads walk them, in the reference's own order of additions
-        if (t >= 4) return;
+        if (t >= 4 || blockIdx.x) return;
         double acc = r_in ? r_in[t] : 0.0;
         if (sums_all)
             for (int q = 0; q < rank; q++) acc += sums_all[q * 4 + t];
@@ -147,42 +151,78 @@ __global__ __launch_bounds__(1024) void mvdr_prefix_kernel(const double *__restr
         if (total) total[t] = sum;
         return;
     }
-    const int per = (n + 1023) >> 10;
-    const int e0 = t * per < n ? t * per : n, e1 = e0 + per < n ? e0 + per : n;
-    double s[4] = {0.0, 0.0, 0.0, 0.0};
-    for (int e = e0; e < e1; e++) {
-        const double4 d = *reinterpret_cast<const double4 *>(delta + (size_t)e * 4);
-        s[0] += d.x; s[1] += d.y; s[2] += d.z; s[3] += d.w;
-    }
+    const int n_tiles = (n + 1023) >> 10;
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int e = tile * 1024 + t;
+        const double4 d = e < n ? *reinterpret_cast<const double4 *>(delta + (size_t)e * 4) : make_double4(0.0, 0.0, 0.0, 0.0);
+        part[0][0][t] = d.x; part[0][1][t] = d.y; part[0][2][t] = d.z; part[0][3][t] = d.w;
+        __syncthreads();
+        int cur = 0;
+        for (int o = 1; o < 1024; o <<= 1) {                          // inclusive scan over the tile
 #pragma unroll
-    for (int c = 0; c < 4; c++) part[0][c][t] = s[c];
-    __syncthreads();
-    int cur = 0;
-    for (int o = 1; o < 1024; o <<= 1) {                          // inclusive scan over the threads
-#pragma unroll
-        for (int c = 0; c < 4; c++) part[cur ^ 1][c][t] = part[cur][c][t] + (t >= o ? part[cur][c][t - o] : 0.0);
-        cur ^= 1;
+            for (int c = 0; c < 4; c++) part[cur ^ 1][c][t] = part[cur][c][t] + (t >= o ? part[cur][c][t - o] : 0.0);
+            cur ^= 1;
+            __syncthreads();
+        }
+        if (rver && e < n)
+            *reinterpret_cast<double4 *>(rver + (size_t)(e + 1) * 4) =
+                make_double4(part[cur][0][t], part[cur][1][t], part[cur][2][t], part[cur][3][t]);
+        if (t < 4) tile_sums[tile * 4 + t] = part[cur][t][1023];
         __syncthreads();
     }
-    double acc[4];
+}
+
+__global__ __launch_bounds__(1024) void mvdr_prefix_bases_kernel(const DenoisePlan *__restrict__ plan,
+                                                                 const int *__restrict__ range, const double *__restrict__ r_in,
+                                                                 const double *__restrict__ sums_all, int rank,
+                                                                 MvdrState *st_out, double *__restrict__ rver,
+                                                                 double *__restrict__ total,
+                                                                 const double *__restrict__ tile_sums)
+{
+    __shared__ double red[4][1024];
+    const int t = threadIdx.x;
+    const int n = range ? range[1] - range[0] : plan->n_events;
+    if (n <= 64) return;
+    const int n_tiles = (n + 1023) >> 10;
+    double r0[4];
 #pragma unroll
     for (int c = 0; c < 4; c++) {
-        double r0 = r_in ? r_in[c] : 0.0;
+        r0[c] = r_in ? r_in[c] : 0.0;
         if (sums_all)
-            for (int q = 0; q < rank; q++) r0 += sums_all[q * 4 + c];
-        if (t == 0 && rver) rver[c] = r0;
-        acc[c] = r0 + (t > 0 ? part[cur][c][t - 1] : 0.0);
+            for (int q = 0; q < rank; q++) r0[c] += sums_all[q * 4 + c];
     }
-    for (int e = e0; e < e1; e++) {
-        const double4 d = *reinterpret_cast<const double4 *>(delta + (size_t)e * 4);
-        acc[0] += d.x; acc[1] += d.y; acc[2] += d.z; acc[3] += d.w;
-        if (rver) *reinterpret_cast<double4 *>(rver + (size_t)(e + 1) * 4) = make_double4(acc[0], acc[1], acc[2], acc[3]);
-    }
-    if (t == 1023) {
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        double s[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int k = t; k < tile; k += 1024) {
+            const double4 d = *reinterpret_cast<const double4 *>(tile_sums + (size_t)k * 4);
+            s[0] += d.x; s[1] += d.y; s[2] += d.z; s[3] += d.w;
+        }
 #pragma unroll
-        for (int c = 0; c < 4; c++) {
-            if (st_out) st_out->corr[c] = acc[c];
-            if (total) total[c] = part[cur][c][1023];
+        for (int c = 0; c < 4; c++) red[c][t] = s[c];
+        __syncthreads();
+        for (int o = 512; o > 0; o >>= 1) {
+            if (t < o) {
+#pragma unroll
+                for (int c = 0; c < 4; c++) red[c][t] += red[c][t + o];
+            }
+            __syncthreads();
+        }
+        const double before[4] = {red[0][0], red[1][0], red[2][0], red[3][0]};      // sum of the tiles before this one
+        __syncthreads();
+        const int e = tile * 1024 + t;
+        if (rver) {
+            if (tile == 0 && t == 0) *reinterpret_cast<double4 *>(rver) = make_double4(r0[0], r0[1], r0[2], r0[3]);
+            if (e < n) {
+                double4 *row = reinterpret_cast<double4 *>(rver + (size_t)(e + 1) * 4);
+                const double4 loc = *row;
+                *row = make_double4((r0[0] + before[0]) + loc.x, (r0[1] + before[1]) + loc.y, (r0[2] + before[2]) + loc.z,
+                                    (r0[3] + before[3]) + loc.w);
+            }
+        }
+        if (tile == n_tiles - 1 && t < 4) {
+            const double tot = before[t] + tile_sums[tile * 4 + t];
+            if (st_out) st_out->corr[t] = r0[t] + tot;
+            if (total) total[t] = tot;
         }
     }
 }
@@ -468,17 +508,27 @@ __global__ __launch_bounds__(64) void mvdr_pairs_kernel(const short *__restrict_
     }
 }
 
+static void launch_mvdr_prefix(hipStream_t s, const double *delta, const DenoisePlan *plan, const int *range,
+                               const double *r_in, const double *sums_all, int rank, MvdrState *st_out, double *rver,
+                               double *total, double *tile_sums)
+{
+    hipLaunchKernelGGL(mvdr_prefix_kernel, dim3(kPrefixGrid), dim3(1024), 0, s, delta, plan, range, r_in, sums_all, rank, st_out,
+                       rver, total, tile_sums);
+    hipLaunchKernelGGL(mvdr_prefix_bases_kernel, dim3(kPrefixGrid), dim3(1024), 0, s, plan, range, r_in, sums_all, rank, st_out,
+                       rver, total, (const double *)tile_sums);
+}
+
 int launch_mvdr(hipStream_t s, const short *left, const short *right, long n_blocks, long calls_before,
                 const MvdrState *st_in, MvdrState *st_out, const int *events, const DenoisePlan *plan,
                 const int *ver_base, const unsigned long long *snap_mask, double *delta, double *rver,
-                const double2 *steer, const float2 *table, short *out, float *precast, float4 *wtab)
+                const double2 *steer, const float2 *table, short *out, float *precast, float4 *wtab,
+                double *tile_sums)
 {
     if (n_blocks <= 0) return 0;
     const long g1 = n_blocks < 2048 ? n_blocks : 2048;
     hipLaunchKernelGGL(mvdr_corr_kernel, dim3((unsigned)g1), dim3(64), 0, s, left, right, n_blocks, st_in, events, plan,
                        table, delta, (const int *)nullptr, 0L);
-    hipLaunchKernelGGL(mvdr_prefix_kernel, dim3(1), dim3(1024), 0, s, delta, plan, (const int *)nullptr, st_in->corr,
-                       (const double *)nullptr, 0, st_out, rver, (double *)nullptr);
+    launch_mvdr_prefix(s, delta, plan, nullptr, st_in->corr, nullptr, 0, st_out, rver, nullptr, tile_sums);
     DenoiseShard sh;
     sh.ver_block_off = 0;
     sh.ver_row_off = nullptr;
@@ -500,14 +550,14 @@ int launch_mvdr(hipStream_t s, const short *left, const short *right, long n_blo
 
 // EstimateSpatialCorrMtx on its own: the deltas of every listed event and their sum (no state touched).
 int launch_mvdr_corr_total(hipStream_t s, const short *left, const short *right, long n_blocks, const MvdrState *st_in,
-                           const int *events, const DenoisePlan *plan, const float2 *table, double *delta, double *total)
+                           const int *events, const DenoisePlan *plan, const float2 *table, double *delta, double *total,
+                           double *tile_sums)
 {
     if (n_blocks <= 0) return 0;
     const long g1 = n_blocks < 2048 ? n_blocks : 2048;
     hipLaunchKernelGGL(mvdr_corr_kernel, dim3((unsigned)g1), dim3(64), 0, s, left, right, n_blocks, st_in, events, plan,
                        table, delta, (const int *)nullptr, 0L);
-    hipLaunchKernelGGL(mvdr_prefix_kernel, dim3(1), dim3(1024), 0, s, delta, plan, (const int *)nullptr, (const double *)nullptr,
-                       (const double *)nullptr, 0, (MvdrState *)nullptr, (double *)nullptr, total);
+    launch_mvdr_prefix(s, delta, plan, nullptr, nullptr, nullptr, 0, nullptr, nullptr, total, tile_sums);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
@@ -548,15 +598,14 @@ __global__ void mvdr_event_range_kernel(const int *__restrict__ events, const De
 int launch_mvdr_shard_summary(hipStream_t s, const short *left_ext, const short *right_ext, long n_ext, long ext0,
                               long b0, long b1, const MvdrState *zero_state, const int *events,
                               const DenoisePlan *plan, const int *ver_base, const unsigned long long *snap_mask,
-                              const float2 *table, int *range, double *delta, double *total)
+                              const float2 *table, int *range, double *delta, double *total, double *tile_sums)
 {
     hipLaunchKernelGGL(mvdr_event_range_kernel, dim3(1), dim3(64), 0, s, events, plan, ver_base, snap_mask, b0, b1, range);
     const long own = b1 - b0;
     const long g1 = own < 2048 ? (own > 0 ? own : 1) : 2048;
     hipLaunchKernelGGL(mvdr_corr_kernel, dim3((unsigned)g1), dim3(64), 0, s, left_ext, right_ext, n_ext, zero_state, events,
                        plan, table, delta, (const int *)range, ext0);
-    hipLaunchKernelGGL(mvdr_prefix_kernel, dim3(1), dim3(1024), 0, s, delta, plan, (const int *)range,
-                       (const double *)nullptr, (const double *)nullptr, 0, (MvdrState *)nullptr, (double *)nullptr, total);
+    launch_mvdr_prefix(s, delta, plan, range, nullptr, nullptr, 0, nullptr, nullptr, total, tile_sums);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
@@ -564,10 +613,9 @@ int launch_mvdr_shard_finish(hipStream_t s, const short *left_ext, const short *
                              long b0, long b1, const MvdrState *zero_state, MvdrState *scratch_state,
                              const DenoisePlan *plan, const int *ver_base, const unsigned long long *snap_mask,
                              const int *range, const double *delta, const double *sums_all, int rank, double *rver,
-                             const double2 *steer, const float2 *table, short *out, float *precast)
+                             const double2 *steer, const float2 *table, short *out, float *precast, double *tile_sums)
 {
-    hipLaunchKernelGGL(mvdr_prefix_kernel, dim3(1), dim3(1024), 0, s, delta, plan, range, (const double *)nullptr, sums_all,
-                       rank, (MvdrState *)nullptr, rver, (double *)nullptr);
+    launch_mvdr_prefix(s, delta, plan, range, nullptr, sums_all, rank, nullptr, rver, nullptr, tile_sums);
     DenoiseShard sh;
     sh.ver_block_off = ext0;
     sh.ver_row_off = range + 2;

@@ -171,6 +171,36 @@ def test_pause_heavy_stream_uses_the_parallel_prefix(eng, oracle):
     m.close()
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_mvdr_sharded_pause_heavy(eng, oracle, world):
+    """Sharded run whose ranks each hold more than a tile (1,024) of estimation events: the tiled prefix with a rank's
+    event range and the earlier ranks' sums carried in."""
+    import torch
+    from jeicyboodsp_amd import sharding
+    nb = 4200
+    quiet = tuple((b0, 21) for b0 in range(0, nb - 25, 24))
+    L, R = stereo(71, nb, quiet=quiet)
+    o_out, _, _, trace = oracle.mvdr_stream(L, R, 1e-4)
+    updated = np.diff(trace[:, 0]) != 0                                  # blocks whose matrix moved = events
+    tl, tr = torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()
+    ranks = []
+    for r in range(world):
+        b0, cnt = sharding.split_even(nb, r, world)
+        assert updated[b0:b0 + cnt].sum() > 1024
+        ext0 = max(b0 - 1, 0)
+        ranks.append(dict(m=eng.mvdr(1e-4), ext0=ext0, b0=b0, b1=b0 + cnt,
+                          l=tl[ext0 * 512:(b0 + cnt) * 512].clone(), r=tr[ext0 * 512:(b0 + cnt) * 512].clone()))
+    flags = torch.cat([k["m"].shard_vad(k["l"], k["r"], k["ext0"], k["b0"], k["b1"], nb) for k in ranks]).contiguous()
+    sums = torch.stack([k["m"].shard_summary(flags) for k in ranks]).contiguous()
+    outs = [k["m"].shard_finish(sums, world, r) for r, k in enumerate(ranks)]
+    torch.cuda.synchronize()
+    got = torch.cat(outs).cpu().numpy()
+    for k in ranks:
+        k["m"].close()
+    assert got.shape == o_out.shape
+    assert np.abs(got.astype(np.int32) - o_out.astype(np.int32)).max() <= 1
+
+
 @pytest.mark.parametrize("n_quiet", [1021, 1024, 1027])
 def test_weight_table_boundary(eng, oracle, n_quiet):
     """Calls with fewer than 1,024 events read their per-bin weights from the per-version table, calls with more compute
