@@ -151,6 +151,23 @@ __global__ __launch_bounds__(64) void mvdrn_chunk_prefix_kernel(const double2 *_
 // One wave owns (bin k, chunk); lane (r, c) = (lane >> 3, lane & 7) owns R_k[r][c].  After every event
 // the weights are recomputed: Gauss-Jordan on [R' | c] across the lanes (R' Hermitian positive
 // definite once loaded, so no pivoting), then w = x / (c^H x).  Version 0 = the matrix carried in (chunk 0).
+// The lanes trade matrix entries through LDS (one 16-byte write, then the pivot, its row and this lane's column entry as
+// 16-byte reads, two of them broadcasts) -- as __shfl of FP64 pairs a solve was ~210 ds_bpermute_b32 at 8.9 issue slots
+// each, and the kernel 87 % of an 8-microphone call at 10 % pauses (profiles/r02_mvdr_pairs.txt).
+#ifndef JDSP_MVN_LDS_SOLVE
+#define JDSP_MVN_LDS_SOLVE 1
+#endif
+__device__ __forceinline__ cd cd_of(double2 a) { return {a.x, a.y}; }
+// 1 / a with one reciprocal: hardware estimate + two Newton steps (relative error ~1e-16: the weights are stored as FP32)
+__device__ __forceinline__ cd cd_inv_fast(cd a)
+{
+    const double d = a.x * a.x + a.y * a.y;
+    double y = __builtin_amdgcn_rcp(d);
+    y = y * (2.0 - d * y);
+    y = y * (2.0 - d * y);
+    return {a.x * y, -a.y * y};
+}
+
 __global__ __launch_bounds__(64) void mvdrn_update_kernel(const float2 *__restrict__ spec, int n_mics, int n_bins,
                                                           double inv_n, const DenoisePlan *__restrict__ plan,
                                                           const double2 *__restrict__ chunk_start,
@@ -169,12 +186,72 @@ __global__ __launch_bounds__(64) void mvdrn_update_kernel(const float2 *__restri
     const cd cr = {r < n_mics ? sr.x : 0.0, r < n_mics ? sr.y : 0.0};
     const int e0 = chunk * g.per_chunk;
     const int e1 = e0 + g.per_chunk < n_events ? e0 + g.per_chunk : n_events;
+#if JDSP_MVN_LDS_SOLVE
+    __shared__ __attribute__((aligned(16))) double2 sA[64];     // the working matrix, entry (r, c) at 8 r + c
+    __shared__ __attribute__((aligned(16))) double2 sb[8];      // the right-hand side, then the solution
+    __shared__ __attribute__((aligned(16))) double2 sc[8];      // the steering vector
+    if (c == 0) sc[r] = make_double2(cr.x, cr.y);
+    const double load_scale = loading / n_mics;
+    // the first event's entries ahead of the loop, every later one while the solve before it runs
+    float2 xr = make_float2(0.f, 0.f), xc = make_float2(0.f, 0.f);
+    const int v0 = chunk == 0 ? 0 : e0 + 1;
+    if (live && e0 < e1) {                                     // event e0 is the first this chunk adds
+        const float2 *ev = spec + (size_t)e0 * n_mics * n_bins + k;
+        xr = ev[(size_t)r * n_bins];
+        xc = ev[(size_t)c * n_bins];
+    }
+    for (int v = v0; v <= e1; v++) {
+        if (v > e0) {
+            // R[r][c] += X_r conj(X_c) / N   (N = 1024 or 512: a power of two, exact)
+            R.x += ((double)xr.x * xc.x + (double)xr.y * xc.y) * inv_n;
+            R.y += ((double)xr.y * xc.x - (double)xr.x * xc.y) * inv_n;
+        }
+        if (live && v < e1) {                                  // event v (0-based) is the one version v + 1 adds
+            const float2 *ev = spec + (size_t)v * n_mics * n_bins + k;
+            xr = ev[(size_t)r * n_bins];
+            xc = ev[(size_t)c * n_bins];
+        }
+        sA[lane] = make_double2(R.x, R.y);
+        wave_lds_fence();
+        double tr = 0.0;
+        for (int d = 0; d < n_mics; d++) tr += sA[9 * d].x;
+        cd A = R;
+        if (live && r == c) A.x += load_scale * tr;
+        if (!live) A = {r == c ? 1.0 : 0.0, 0.0};
+        cd b = cr;
+        for (int p = 0; p < n_mics; p++) {
+            wave_lds_fence();
+            sA[lane] = make_double2(A.x, A.y);
+            if (c == 0) sb[r] = make_double2(b.x, b.y);
+            wave_lds_fence();
+            const cd inv = cd_inv_fast(cd_of(sA[9 * p]));
+            const cd rowp = cd_mul(cd_of(sA[8 * p + c]), inv);
+            const cd bp = cd_mul(cd_of(sb[p]), inv);
+            const cd f = cd_of(sA[8 * r + p]);
+            if (r == p) { A = rowp; b = bp; }
+            else { A = cd_sub(A, cd_mul(f, rowp)); b = cd_sub(b, cd_mul(f, bp)); }
+        }
+        wave_lds_fence();
+        if (c == 0) sb[r] = make_double2(b.x, b.y);
+        wave_lds_fence();
+        cd den = {0.0, 0.0};                                   // c^H x
+        for (int d = 0; d < n_mics; d++) {
+            const cd xd = cd_of(sb[d]);
+            const cd cdv = cd_of(sc[d]);
+            den.x += cdv.x * xd.x + cdv.y * xd.y;
+            den.y += cdv.x * xd.y - cdv.y * xd.x;
+        }
+        const cd w = cd_mul(b, cd_inv_fast(den));
+        // [version][microphone][bin]: the apply kernel reads one microphone's weights for consecutive bins
+        if (c == 0 && r < n_mics) weights[((size_t)v * 8 + r) * n_bins + k] = make_float2((float)w.x, (float)w.y);
+        wave_lds_fence();
+    }
+#else
     for (int v = chunk == 0 ? 0 : e0 + 1; v <= e1; v++) {
         if (v > e0) {
             const float2 *ev = spec + (size_t)(v - 1) * n_mics * n_bins + k;
             const float2 xr = live ? ev[(size_t)r * n_bins] : make_float2(0.f, 0.f);
             const float2 xc = live ? ev[(size_t)c * n_bins] : make_float2(0.f, 0.f);
-            // R[r][c] += X_r conj(X_c) / N   (N = 1024 or 512: a power of two, exact)
             R.x += ((double)xr.x * xc.x + (double)xr.y * xc.y) * inv_n;
             R.y += ((double)xr.y * xc.x - (double)xr.x * xc.y) * inv_n;
         }
@@ -200,9 +277,9 @@ __global__ __launch_bounds__(64) void mvdrn_update_kernel(const float2 *__restri
             den.y += cdv.x * xd.y - cdv.y * xd.x;
         }
         const cd w = cd_mul(b, cd_inv(den));
-        // [version][microphone][bin]: the apply kernel reads one microphone's weights for consecutive bins
         if (c == 0 && r < n_mics) weights[((size_t)v * 8 + r) * n_bins + k] = make_float2((float)w.x, (float)w.y);
     }
+#endif
 }
 
 __global__ __launch_bounds__(64) void mvdrn_apply_kernel(const short *__restrict__ pcm, long chan_stride, int n_mics,

@@ -69,10 +69,12 @@ def main():
             print(json.dumps({"chain": "mvdr_2mic", "blocks": B, "pause_frac": pause_frac, "quiet_blocks": n_quiet,
                               "us_per_call": round(ms * 1e3, 1)}), flush=True)
             mv.close()
-        if a.case >= 0:
+        if a.case >= 0 and a.case < 10:
             return
         nb = 16384
-        for pause_frac, mean_run in ((0.0, 0), (0.01, 20), (0.1, 20)):
+        for i, (pause_frac, mean_run) in enumerate(((0.0, 0), (0.01, 20), (0.1, 20))):
+            if a.case >= 10 and i != a.case - 10:                     # --case 10..12: one 8-microphone setting
+                continue
             x, n_quiet = stream(rng, nb, 512, pause_frac, mean_run)
             mics = np.stack([np.roll(x, 2 * m) for m in range(8)])
             tm = torch.from_numpy(mics).cuda()
