@@ -74,7 +74,7 @@ struct DenoiseShard {
 
 // BeamForming_MVDR_ver1.cpp's state between calls (device memory)
 constexpr int kMvdrTableVersions = 1024;     // 2-microphone MVDR: calls with fewer events than this get their weights from a table
-constexpr int kMvnChunks = 32;             // chunks the n-microphone covariance update cuts a call's events into
+constexpr int kMvnChunks = 128;            // chunks the n-microphone covariance update cuts a call's events into
 
 struct MvdrState {
     int run_len;          // main(): iNumOfIteration             MVDR:59,99,108

@@ -92,11 +92,17 @@ __device__ __forceinline__ cd cd_shfl(cd a, int src) { return {__shfl(a.x, src),
 
 // The covariance after every estimation frame and the weights that go with it.  R_k after event e is a prefix sum
 // over the events and every (bin, version) solve is independent, so the event list is cut into kMvnChunks chunks:
-//   mvdrn_chunk_sums_kernel    (bin, chunk): the chunk's sum of X X^H / N
+//   mvdrn_chunk_sums_kernel    (8 bins, chunk): the chunk's sum of X X^H / N
 //   mvdrn_chunk_prefix_kernel  (bin): the matrix entering every chunk, and the one carried out of the call
-//   mvdrn_update_kernel        (bin, chunk): walks the chunk's events from its entering matrix, one solve per event
+//   mvdrn_update_kernel        (8 bins, chunk): walks the chunk's events from its entering matrix, one solve per event
 // (One wave per bin walking the whole list took 3.6 us per event: 5.9 ms at 10 % pauses in 16,384 blocks,
 // profiles/r02_denoise_events.txt.)  FP64 sums: the grouping moves nothing above 1e-16.
+//
+// A wave holds EIGHT bins, one matrix ROW per lane (lane = 8 * bin-in-wave + row, the row's eight entries in
+// registers).  With one ENTRY per lane (a bin per wave) every lane repeated the pivot's reciprocal and the right-hand
+// side's update -- 17 of the 25 FP64 operations of an elimination step -- and a step was a round of exchanges per
+// bin; a row per lane shares them between eight bins and lets step p touch only the columns right of p
+// (profiles/r02_mvdr_pairs.txt).
 struct MvnChunks { int per_chunk, n_chunks; };
 __device__ __forceinline__ MvnChunks mvn_chunks(int n_events)
 {
@@ -106,26 +112,61 @@ __device__ __forceinline__ MvnChunks mvn_chunks(int n_events)
     return g;
 }
 
+__device__ __forceinline__ cd cd_of(double2 a) { return {a.x, a.y}; }
+__device__ __forceinline__ double2 d2_of(cd a) { return make_double2(a.x, a.y); }
+// 1 / a with one reciprocal: hardware estimate + two Newton steps (relative error ~1e-16: the weights are stored as FP32)
+__device__ __forceinline__ cd cd_inv_fast(cd a)
+{
+    const double d = a.x * a.x + a.y * a.y;
+    double y = __builtin_amdgcn_rcp(d);
+    y = y * (2.0 - d * y);
+    y = y * (2.0 - d * y);
+    return {a.x * y, -a.y * y};
+}
+
+// this lane's spectrum value to its group, the group's eight back: row[c] += X_r conj(X_c) / N   (N a power of two: exact)
+__device__ __forceinline__ void mvn_row_add(cd (&row)[8], float2 xr, float2 *xs, int r, double inv_n)
+{
+    wave_lds_fence();
+    xs[r] = xr;
+    wave_lds_fence();
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const float4 two = *reinterpret_cast<const float4 *>(&xs[2 * q]);
+        row[2 * q].x += ((double)xr.x * two.x + (double)xr.y * two.y) * inv_n;
+        row[2 * q].y += ((double)xr.y * two.x - (double)xr.x * two.y) * inv_n;
+        row[2 * q + 1].x += ((double)xr.x * two.z + (double)xr.y * two.w) * inv_n;
+        row[2 * q + 1].y += ((double)xr.y * two.z - (double)xr.x * two.w) * inv_n;
+    }
+}
+
 __global__ __launch_bounds__(64) void mvdrn_chunk_sums_kernel(const float2 *__restrict__ spec, int n_mics, int n_bins,
                                                               double inv_n, const DenoisePlan *__restrict__ plan,
                                                               double2 *__restrict__ chunk_sum)
 {
-    const int k = blockIdx.x, chunk = blockIdx.y, lane = threadIdx.x;
+    __shared__ __attribute__((aligned(16))) float2 sx[8][8];
+    const int lane = threadIdx.x, grp = lane >> 3, r = lane & 7, chunk = blockIdx.y;
     const int n_events = plan->n_events;
     const MvnChunks g = mvn_chunks(n_events);
     if (chunk >= g.n_chunks) return;
-    const int r = lane >> 3, c = lane & 7;
-    const bool live = r < n_mics && c < n_mics;
+    const int kb = blockIdx.x * 8 + grp;
+    const int k = kb < n_bins ? kb : n_bins - 1;                 // a group past the last bin repeats it and stores nothing
     const int e0 = chunk * g.per_chunk, e1 = e0 + g.per_chunk < n_events ? e0 + g.per_chunk : n_events;
-    double sx = 0.0, sy = 0.0;
+    cd S[8];
+#pragma unroll
+    for (int c = 0; c < 8; c++) S[c] = {0.0, 0.0};
+    float2 xr = make_float2(0.f, 0.f);
+    if (r < n_mics && e0 < e1) xr = spec[((size_t)e0 * n_mics + r) * n_bins + k];
     for (int e = e0; e < e1; e++) {
-        const float2 *ev = spec + (size_t)e * n_mics * n_bins + k;
-        const float2 xr = live ? ev[(size_t)r * n_bins] : make_float2(0.f, 0.f);
-        const float2 xc = live ? ev[(size_t)c * n_bins] : make_float2(0.f, 0.f);
-        sx += ((double)xr.x * xc.x + (double)xr.y * xc.y) * inv_n;
-        sy += ((double)xr.y * xc.x - (double)xr.x * xc.y) * inv_n;
+        const float2 x = xr;
+        if (r < n_mics && e + 1 < e1) xr = spec[((size_t)(e + 1) * n_mics + r) * n_bins + k];
+        mvn_row_add(S, x, sx[grp], r, inv_n);
     }
-    chunk_sum[((size_t)chunk * n_bins + k) * 64 + lane] = make_double2(sx, sy);
+    if (kb < n_bins) {
+        double2 *dst = chunk_sum + ((size_t)chunk * n_bins + k) * 64 + 8 * r;
+#pragma unroll
+        for (int c = 0; c < 8; c++) dst[c] = d2_of(S[c]);
+    }
 }
 
 __global__ __launch_bounds__(64) void mvdrn_chunk_prefix_kernel(const double2 *__restrict__ chunk_sum, int n_mics, int n_bins,
@@ -139,147 +180,112 @@ __global__ __launch_bounds__(64) void mvdrn_chunk_prefix_kernel(const double2 *_
     const double2 rin = cov_in[(size_t)k * 64 + lane];
     double2 R = make_double2(live ? rin.x : 0.0, live ? rin.y : 0.0);
     chunk_start[(size_t)k * 64 + lane] = R;                       // chunk 0 exists even without events: version 0
-    for (int c = 0; c < g.n_chunks; c++) {
-        if (c > 0) chunk_start[((size_t)c * n_bins + k) * 64 + lane] = R;
-        const double2 s = chunk_sum[((size_t)c * n_bins + k) * 64 + lane];
-        R.x += s.x;
-        R.y += s.y;
+    for (int c0 = 0; c0 < g.n_chunks; c0 += 8) {                  // eight sums in flight: the walk is latency, not arithmetic
+        double2 s[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+            s[i] = c0 + i < g.n_chunks ? chunk_sum[((size_t)(c0 + i) * n_bins + k) * 64 + lane] : make_double2(0.0, 0.0);
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            if (c0 + i >= g.n_chunks) break;
+            if (c0 + i > 0) chunk_start[((size_t)(c0 + i) * n_bins + k) * 64 + lane] = R;
+            R.x += s[i].x;
+            R.y += s[i].y;
+        }
     }
     cov_out[(size_t)k * 64 + lane] = R;
 }
 
-// One wave owns (bin k, chunk); lane (r, c) = (lane >> 3, lane & 7) owns R_k[r][c].  After every event
-// the weights are recomputed: Gauss-Jordan on [R' | c] across the lanes (R' Hermitian positive
-// definite once loaded, so no pivoting), then w = x / (c^H x).  Version 0 = the matrix carried in (chunk 0).
-// The lanes trade matrix entries through LDS (one 16-byte write, then the pivot, its row and this lane's column entry as
-// 16-byte reads, two of them broadcasts) -- as __shfl of FP64 pairs a solve was ~210 ds_bpermute_b32 at 8.9 issue slots
-// each, and the kernel 87 % of an 8-microphone call at 10 % pauses (profiles/r02_mvdr_pairs.txt).
-#ifndef JDSP_MVN_LDS_SOLVE
-#define JDSP_MVN_LDS_SOLVE 1
-#endif
-__device__ __forceinline__ cd cd_of(double2 a) { return {a.x, a.y}; }
-// 1 / a with one reciprocal: hardware estimate + two Newton steps (relative error ~1e-16: the weights are stored as FP32)
-__device__ __forceinline__ cd cd_inv_fast(cd a)
-{
-    const double d = a.x * a.x + a.y * a.y;
-    double y = __builtin_amdgcn_rcp(d);
-    y = y * (2.0 - d * y);
-    y = y * (2.0 - d * y);
-    return {a.x * y, -a.y * y};
-}
-
+// After every event the weights are recomputed: Gaussian elimination of [R' | c] to a diagonal (R' = R + loading *
+// tr(R) / n * I, Hermitian positive definite once loaded, so no pivoting; pivot rows are left unnormalised and each
+// unknown is divided by its pivot at the end), then w = x / (c^H x).  Version 0 = the matrix carried in (chunk 0).
+// Step p: the lane holding row p puts its entries right of the diagonal and its right-hand side in LDS, the group's
+// other rows subtract their multiple of it.
 __global__ __launch_bounds__(64) void mvdrn_update_kernel(const float2 *__restrict__ spec, int n_mics, int n_bins,
                                                           double inv_n, const DenoisePlan *__restrict__ plan,
                                                           const double2 *__restrict__ chunk_start,
                                                           const double2 *__restrict__ steer, double loading,
                                                           float2 *__restrict__ weights)
 {
-    const int k = blockIdx.x, chunk = blockIdx.y, lane = threadIdx.x;
+    __shared__ __attribute__((aligned(16))) float2 sx[8][8];       // the event's spectra, [bin in wave][microphone]
+    __shared__ __attribute__((aligned(16))) double2 srow[8][9];    // the pivot row and its right-hand side
+    __shared__ __attribute__((aligned(16))) double2 sc[8][8];      // steering vectors
+    __shared__ __attribute__((aligned(16))) double2 sv[8][8];      // diagonals, then the unknowns
+    const int lane = threadIdx.x, grp = lane >> 3, r = lane & 7, chunk = blockIdx.y;
     const int n_events = plan->n_events;
     const MvnChunks g = mvn_chunks(n_events);
     if (chunk > 0 && chunk >= g.n_chunks) return;
-    const int r = lane >> 3, c = lane & 7;
-    const bool live = r < n_mics && c < n_mics;
-    const double2 rin = chunk_start[((size_t)chunk * n_bins + k) * 64 + lane];
-    cd R = {rin.x, rin.y};
+    const int kb = blockIdx.x * 8 + grp;
+    const int k = kb < n_bins ? kb : n_bins - 1;
+    const bool row_live = r < n_mics;
+    cd R[8];
+    {
+        const double2 *src = chunk_start + ((size_t)chunk * n_bins + k) * 64 + 8 * r;
+#pragma unroll
+        for (int c = 0; c < 8; c++) R[c] = cd_of(src[c]);
+    }
     const double2 sr = steer[(size_t)k * 8 + r];
-    const cd cr = {r < n_mics ? sr.x : 0.0, r < n_mics ? sr.y : 0.0};
+    const cd cr = {row_live ? sr.x : 0.0, row_live ? sr.y : 0.0};
+    sc[grp][r] = d2_of(cr);
     const int e0 = chunk * g.per_chunk;
     const int e1 = e0 + g.per_chunk < n_events ? e0 + g.per_chunk : n_events;
-#if JDSP_MVN_LDS_SOLVE
-    __shared__ __attribute__((aligned(16))) double2 sA[64];     // the working matrix, entry (r, c) at 8 r + c
-    __shared__ __attribute__((aligned(16))) double2 sb[8];      // the right-hand side, then the solution
-    __shared__ __attribute__((aligned(16))) double2 sc[8];      // the steering vector
-    if (c == 0) sc[r] = make_double2(cr.x, cr.y);
-    const double load_scale = loading / n_mics;
-    // the first event's entries ahead of the loop, every later one while the solve before it runs
-    float2 xr = make_float2(0.f, 0.f), xc = make_float2(0.f, 0.f);
-    const int v0 = chunk == 0 ? 0 : e0 + 1;
-    if (live && e0 < e1) {                                     // event e0 is the first this chunk adds
-        const float2 *ev = spec + (size_t)e0 * n_mics * n_bins + k;
-        xr = ev[(size_t)r * n_bins];
-        xc = ev[(size_t)c * n_bins];
-    }
-    for (int v = v0; v <= e1; v++) {
-        if (v > e0) {
-            // R[r][c] += X_r conj(X_c) / N   (N = 1024 or 512: a power of two, exact)
-            R.x += ((double)xr.x * xc.x + (double)xr.y * xc.y) * inv_n;
-            R.y += ((double)xr.y * xc.x - (double)xr.x * xc.y) * inv_n;
-        }
-        if (live && v < e1) {                                  // event v (0-based) is the one version v + 1 adds
-            const float2 *ev = spec + (size_t)v * n_mics * n_bins + k;
-            xr = ev[(size_t)r * n_bins];
-            xc = ev[(size_t)c * n_bins];
-        }
-        sA[lane] = make_double2(R.x, R.y);
-        wave_lds_fence();
-        double tr = 0.0;
-        for (int d = 0; d < n_mics; d++) tr += sA[9 * d].x;
-        cd A = R;
-        if (live && r == c) A.x += load_scale * tr;
-        if (!live) A = {r == c ? 1.0 : 0.0, 0.0};
-        cd b = cr;
-        for (int p = 0; p < n_mics; p++) {
-            wave_lds_fence();
-            sA[lane] = make_double2(A.x, A.y);
-            if (c == 0) sb[r] = make_double2(b.x, b.y);
-            wave_lds_fence();
-            const cd inv = cd_inv_fast(cd_of(sA[9 * p]));
-            const cd rowp = cd_mul(cd_of(sA[8 * p + c]), inv);
-            const cd bp = cd_mul(cd_of(sb[p]), inv);
-            const cd f = cd_of(sA[8 * r + p]);
-            if (r == p) { A = rowp; b = bp; }
-            else { A = cd_sub(A, cd_mul(f, rowp)); b = cd_sub(b, cd_mul(f, bp)); }
-        }
-        wave_lds_fence();
-        if (c == 0) sb[r] = make_double2(b.x, b.y);
-        wave_lds_fence();
-        cd den = {0.0, 0.0};                                   // c^H x
-        for (int d = 0; d < n_mics; d++) {
-            const cd xd = cd_of(sb[d]);
-            const cd cdv = cd_of(sc[d]);
-            den.x += cdv.x * xd.x + cdv.y * xd.y;
-            den.y += cdv.x * xd.y - cdv.y * xd.x;
-        }
-        const cd w = cd_mul(b, cd_inv_fast(den));
-        // [version][microphone][bin]: the apply kernel reads one microphone's weights for consecutive bins
-        if (c == 0 && r < n_mics) weights[((size_t)v * 8 + r) * n_bins + k] = make_float2((float)w.x, (float)w.y);
-        wave_lds_fence();
-    }
-#else
+    float2 xr = make_float2(0.f, 0.f);
+    if (row_live && e0 < e1) xr = spec[((size_t)e0 * n_mics + r) * n_bins + k];     // event e0 is the first this chunk adds
     for (int v = chunk == 0 ? 0 : e0 + 1; v <= e1; v++) {
-        if (v > e0) {
-            const float2 *ev = spec + (size_t)(v - 1) * n_mics * n_bins + k;
-            const float2 xr = live ? ev[(size_t)r * n_bins] : make_float2(0.f, 0.f);
-            const float2 xc = live ? ev[(size_t)c * n_bins] : make_float2(0.f, 0.f);
-            R.x += ((double)xr.x * xc.x + (double)xr.y * xc.y) * inv_n;
-            R.y += ((double)xr.y * xc.x - (double)xr.x * xc.y) * inv_n;
-        }
+        if (v > e0) mvn_row_add(R, xr, sx[grp], r, inv_n);
+        if (row_live && v < e1) xr = spec[((size_t)v * n_mics + r) * n_bins + k];   // event v is the one version v + 1 adds
+        double dgx = R[0].x;                                   // the diagonal entry (real) of this lane's row
+#pragma unroll
+        for (int c = 1; c < 8; c++) dgx = r == c ? R[c].x : dgx;
+        wave_lds_fence();
+        sv[grp][r] = make_double2(dgx, 0.0);
+        wave_lds_fence();
         double tr = 0.0;
-        for (int d = 0; d < n_mics; d++) tr += __shfl(R.x, 9 * d);
-        cd A = R;
-        if (live && r == c) A.x += loading * tr / n_mics;
-        if (!live) A = {r == c ? 1.0 : 0.0, 0.0};
-        cd b = cr;
-        for (int p = 0; p < n_mics; p++) {
-            const cd inv = cd_inv(cd_shfl(A, 9 * p));
-            const cd rowp = cd_mul(cd_shfl(A, 8 * p + c), inv);
-            const cd bp = cd_mul(cd_shfl(b, 8 * p), inv);
-            const cd f = cd_shfl(A, 8 * r + p);
-            if (r == p) { A = rowp; b = bp; }
-            else { A = cd_sub(A, cd_mul(f, rowp)); b = cd_sub(b, cd_mul(f, bp)); }
+        for (int d = 0; d < n_mics; d++) tr += sv[grp][d].x;
+        const double load = loading * tr / n_mics;
+        cd A[8];
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+            A[c].x = r == c ? (row_live ? R[c].x + load : 1.0) : R[c].x;
+            A[c].y = r == c && !row_live ? 0.0 : R[c].y;
         }
+        cd b = cr, my_inv = {1.0, 0.0};
+#pragma unroll
+        for (int p = 0; p < 8; p++) {
+            if (p < n_mics) {
+                wave_lds_fence();
+                if (r == p) {
+#pragma unroll
+                    for (int c = p; c < 8; c++) srow[grp][c] = d2_of(A[c]);
+                    srow[grp][8] = d2_of(b);
+                }
+                wave_lds_fence();
+                const cd inv = cd_inv_fast(cd_of(srow[grp][p]));
+                cd f = cd_mul(A[p], inv);                       // this row's multiple of the pivot row
+                my_inv.x = r == p ? inv.x : my_inv.x;
+                my_inv.y = r == p ? inv.y : my_inv.y;
+                f.x = r == p ? 0.0 : f.x;
+                f.y = r == p ? 0.0 : f.y;
+#pragma unroll
+                for (int c = p + 1; c < 8; c++) A[c] = cd_sub(A[c], cd_mul(f, cd_of(srow[grp][c])));
+                b = cd_sub(b, cd_mul(f, cd_of(srow[grp][8])));
+            }
+        }
+        const cd x = cd_mul(b, my_inv);
+        wave_lds_fence();
+        sv[grp][r] = d2_of(x);
+        wave_lds_fence();
         cd den = {0.0, 0.0};                                   // c^H x
         for (int d = 0; d < n_mics; d++) {
-            const cd xd = cd_shfl(b, 8 * d);
-            const cd cdv = cd_shfl(cr, 8 * d);
+            const cd xd = cd_of(sv[grp][d]);
+            const cd cdv = cd_of(sc[grp][d]);
             den.x += cdv.x * xd.x + cdv.y * xd.y;
             den.y += cdv.x * xd.y - cdv.y * xd.x;
         }
-        const cd w = cd_mul(b, cd_inv(den));
-        if (c == 0 && r < n_mics) weights[((size_t)v * 8 + r) * n_bins + k] = make_float2((float)w.x, (float)w.y);
+        const cd w = cd_mul(x, cd_inv_fast(den));
+        // [version][microphone][bin]: the apply kernel reads one microphone's weights for consecutive bins
+        if (row_live && kb < n_bins) weights[((size_t)v * 8 + r) * n_bins + k] = make_float2((float)w.x, (float)w.y);
     }
-#endif
 }
 
 __global__ __launch_bounds__(64) void mvdrn_apply_kernel(const short *__restrict__ pcm, long chan_stride, int n_mics,
@@ -366,9 +372,9 @@ static void launch_mvdrn_update(hipStream_t s, const float2 *spec, int n_mics, i
                                 float2 *weights)
 {
     double2 *sums = chunk_ws, *start = chunk_ws + (size_t)kMvnChunks * n_bins * 64;
-    hipLaunchKernelGGL(mvdrn_chunk_sums_kernel, dim3(n_bins, kMvnChunks), dim3(64), 0, s, spec, n_mics, n_bins, inv_n, plan, sums);
+    hipLaunchKernelGGL(mvdrn_chunk_sums_kernel, dim3((n_bins + 7) / 8, kMvnChunks), dim3(64), 0, s, spec, n_mics, n_bins, inv_n, plan, sums);
     hipLaunchKernelGGL(mvdrn_chunk_prefix_kernel, dim3(n_bins), dim3(64), 0, s, sums, n_mics, n_bins, plan, cov_in, cov_out, start);
-    hipLaunchKernelGGL(mvdrn_update_kernel, dim3(n_bins, kMvnChunks), dim3(64), 0, s, spec, n_mics, n_bins, inv_n, plan, start,
+    hipLaunchKernelGGL(mvdrn_update_kernel, dim3((n_bins + 7) / 8, kMvnChunks), dim3(64), 0, s, spec, n_mics, n_bins, inv_n, plan, start,
                        steer, loading, weights);
 }
 
