@@ -3,11 +3,11 @@
 // has 2 microphones and ONE real 2x2 matrix for all bins -- that exact algorithm is
 // mvdr_kernels.hip; this file keeps its framing, VAD, run counter and weight formula
 // (w = R^-1 c / (c^H R^-1 c), :170-171) and makes R a Hermitian n_mics x n_mics matrix per bin.
-// No MFMA: 8x8 systems, one per bin, solved by Gauss-Jordan across the 64 lanes of a wave in FP64.
+// No MFMA: 8x8 systems, one per bin, eight of them per wave (a matrix row per lane), eliminated in FP64.
 //
 //   vad_kernel / plan_kernel (denoise_kernels.hip)   as for the 2-microphone path
 //   mvdrn_event_spectra_kernel    X_m[k], k = 0..512, of every estimation frame and microphone
-//   mvdrn_update_kernel           one wave per bin: R_k += X X^H / 1024 per event, weights after each
+//   mvdrn_chunk_sums / _prefix / mvdrn_update_kernel   R_k += X X^H / N per event, the weights after each
 //   mvdrn_apply_kernel            one wave per block: n_mics transforms, y = IDFT(w^H X)
 #include "frame_io.h"
 #include "jdsp_internal.h"
@@ -87,8 +87,6 @@ __global__ __launch_bounds__(64) void mvdrn_event_spectra_kernel(const short *__
 struct cd { double x, y; };
 __device__ __forceinline__ cd cd_mul(cd a, cd b) { return {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
 __device__ __forceinline__ cd cd_sub(cd a, cd b) { return {a.x - b.x, a.y - b.y}; }
-__device__ __forceinline__ cd cd_inv(cd a) { const double d = a.x * a.x + a.y * a.y; return {a.x / d, -a.y / d}; }
-__device__ __forceinline__ cd cd_shfl(cd a, int src) { return {__shfl(a.x, src), __shfl(a.y, src)}; }
 
 // The covariance after every estimation frame and the weights that go with it.  R_k after event e is a prefix sum
 // over the events and every (bin, version) solve is independent, so the event list is cut into kMvnChunks chunks:
