@@ -364,6 +364,88 @@ __global__ __launch_bounds__(64) void mvdrn_apply_kernel(const short *__restrict
     }
 }
 
+// The same with pair-owned bins (frame_io.h): lane l works on the bins m, m + 512 of m = l + 64 d, d < 5.  Y[k] =
+// sum_m conj(w_k[m]) X_m[k] with w_k = conj(w_{1024-k}) above 512 is Hermitian when the X_m are, so the 513 bins the
+// five items cover are all of it: ten weights and ten products per lane and microphone instead of sixteen, and the
+// inverse transform's mirrored inputs come from presplit_inv_pair.
+#ifndef JDSP_MVN_APPLY_PAIRS
+#define JDSP_MVN_APPLY_PAIRS 1
+#endif
+__global__ __launch_bounds__(64) void mvdrn_apply_pairs_kernel(const short *__restrict__ pcm, long chan_stride, int n_mics,
+                                                               long n_blocks, long calls_before,
+                                                               const short *__restrict__ prev_in, short *__restrict__ prev_out,
+                                                               const int *__restrict__ ver_base,
+                                                               const unsigned long long *__restrict__ snap_mask,
+                                                               const float2 *__restrict__ weights,
+                                                               const float2 *__restrict__ table, short *__restrict__ out,
+                                                               float *__restrict__ precast)
+{
+    __shared__ __attribute__((aligned(16))) float2 lds[kWaveLdsComplex];
+    __shared__ __attribute__((aligned(16))) unsigned int stage32[528];
+    const int lane = threadIdx.x;
+    const long per_xcd = (gridDim.x + 7) >> 3;
+    const long j = (long)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (j >= n_blocks) return;
+    WaveTwiddles tw;
+    load_wave_twiddles(tw, table, lane);
+    PairTwiddles pw;
+    load_pair_twiddles(pw, table, lane);
+    const bool have_prev = calls_before + j > 0;
+    const float2 *W = weights + (size_t)version_of(ver_base, snap_mask, j) * kMvnBins * 8;
+    const float nyq = lane == 0 ? -1.f : 1.f;                      // k = 512 (lane 0, d = 0) is its own mirror: conj(w) there
+
+    float2 ylo[5], yhi[5];
+#pragma unroll
+    for (int d = 0; d < 5; d++) { ylo[d] = make_float2(0.f, 0.f); yhi[d] = make_float2(0.f, 0.f); }
+    for (int m = 0; m < n_mics; m++) {
+        const short *chan = pcm + (size_t)m * chan_stride;
+        const short *prev = prev_in + (size_t)m * 512;
+        const float2 *Wm = W + (size_t)m * kMvnBins;
+        float2 wl[5], wh[5];
+#pragma unroll
+        for (int d = 0; d < 5; d++) { wl[d] = Wm[lane + 64 * d]; wh[d] = Wm[512 - lane - 64 * d]; }
+        float2 v[8], zr[5];
+        mvdr_frame_pairs(stage32, lane, mvn_block(chan, n_blocks, prev, have_prev ? j - 1 : -2, lane),
+                         mvn_block(chan, n_blocks, prev, j, lane), v, 0.5f);
+        wave_fft512<false>(v, lds, lane, tw);
+        wave_lds_fence();
+        pair_fetch_lds(v, lds, lane, zr);
+#pragma unroll
+        for (int d = 0; d < 5; d++) {
+            const float2 e = cadd_conj(v[d], zr[d]), o = csub_conj_mj(v[d], zr[d]);
+            const float2 t = cmul(pw.w[d], o);
+            const float2 lo = cadd(e, t), hi = csub(e, t);         // X[m], X[m + 512]
+            ylo[d].x += wl[d].x * lo.x + wl[d].y * lo.y;           // conj(w_m) X[m]
+            ylo[d].y += wl[d].x * lo.y - wl[d].y * lo.x;
+            const float why = d == 0 ? nyq * wh[d].y : wh[d].y;
+            yhi[d].x += wh[d].x * hi.x - why * hi.y;               // w_{512-m} X[m + 512]
+            yhi[d].y += wh[d].x * hi.y + why * hi.x;
+        }
+        if (j == n_blocks - 1)
+            reinterpret_cast<u32x4 *>(prev_out + (size_t)m * 512)[lane] = reinterpret_cast<const u32x4 *>(chan + j * 512)[lane];
+    }
+    float2 y[8], ret[4];
+#pragma unroll
+    for (int d = 0; d < 5; d++) {
+        if (d < 4) presplit_inv_pair(ylo[d], yhi[d], pw.w[d], y[d], ret[d]);
+        else y[d] = presplit_inv_reg(ylo[d], yhi[d], pw.w[d]);
+    }
+    pair_return_lds(ret, lds, lane, y);
+    wave_fft512<true>(y, lds, lane, tw);
+    const long first_emit = calls_before >= 1 ? 0 : 1;
+    if (j >= first_emit) {
+        short *o = out + (j - first_emit) * 512;
+        float *pc = precast ? precast + (j - first_emit) * 512 : nullptr;
+#pragma unroll
+        for (int dd = 0; dd < 8; dd++) {
+            const int i0 = 2 * lane + 128 * dd - 511;
+            const float s0 = y[dd].x * (1.0f / 1024.0f), s1 = y[dd].y * (1.0f / 1024.0f);
+            if (i0 >= 0 && i0 < 512) { o[i0] = (short)cast_i16_bits(s0); if (pc) pc[i0] = s0; }
+            if (i0 + 1 >= 0 && i0 + 1 < 512) { o[i0 + 1] = (short)cast_i16_bits(s1); if (pc) pc[i0 + 1] = s1; }
+        }
+    }
+}
+
 // chunk_ws: 2 * kMvnChunks * n_bins * 64 double2 (the chunk sums, then the matrices entering the chunks)
 static void launch_mvdrn_update(hipStream_t s, const float2 *spec, int n_mics, int n_bins, double inv_n, const DenoisePlan *plan,
                                 const double2 *cov_in, double2 *cov_out, double2 *chunk_ws, const double2 *steer, double loading,
@@ -388,8 +470,13 @@ int launch_mvdrn(hipStream_t s, const short *pcm, long chan_stride, int n_mics, 
                        prev_in, events, plan, table, spec);
     launch_mvdrn_update(s, spec, n_mics, kMvnBins, 1.0 / 1024.0, plan, cov_in, cov_out, chunk_ws, steer, loading, weights);
     const long grid = (n_blocks + 7) / 8 * 8;
+#if JDSP_MVN_APPLY_PAIRS
+    hipLaunchKernelGGL(mvdrn_apply_pairs_kernel, dim3((unsigned)grid), dim3(64), 0, s, pcm, chan_stride, n_mics, n_blocks,
+                       calls_before, prev_in, prev_out, ver_base, snap_mask, weights, table, out, precast);
+#else
     hipLaunchKernelGGL(mvdrn_apply_kernel, dim3((unsigned)grid), dim3(64), 0, s, pcm, chan_stride, n_mics, n_blocks,
                        calls_before, prev_in, prev_out, ver_base, snap_mask, weights, table, out, precast);
+#endif
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
