@@ -329,7 +329,12 @@ __global__ __launch_bounds__(64) void mvdr_kernel(const short *__restrict__ left
     wave_fft512<true>(y, lds, lane, tw);
 
     const long first_emit = sh.emit_from;                           // :201-204: the first call's block is dropped
+#if JDSP_MVDR_ABLATE == 3                                   // timing only: one store per lane
+    if (y[0].x + y[3].y + y[5].x + y[7].y == 1.2345f) out[lane] = 1;
+    if (false) {
+#else
     if (j >= first_emit && j < sh.emit_to) {
+#endif
         short *o = out + (j - first_emit) * 512;
         float *pc = precast ? precast + (j - first_emit) * 512 : nullptr;
 #pragma unroll
@@ -361,6 +366,9 @@ __global__ __launch_bounds__(64) void mvdr_kernel(const short *__restrict__ left
 //    Z'[512 - m] cross lanes.
 #ifndef JDSP_MVDR_PAIRS
 #define JDSP_MVDR_PAIRS 1
+#endif
+#ifndef JDSP_MVDR_ABLATE
+#define JDSP_MVDR_ABLATE 0      // 1..4: timing-only builds that drop one part of mvdr_pairs_kernel (tools/build_variant.sh)
 #endif
 struct MvdrInv { double i00, i01, i10, i11; };
 
@@ -445,6 +453,10 @@ __global__ __launch_bounds__(64) void mvdr_pairs_kernel(const short *__restrict_
         llo[d] = cadd(e, t);
         lhi[d] = csub(e, t);
     }
+#if JDSP_MVDR_ABLATE == 2                                   // timing only: no second forward transform
+#pragma unroll
+    for (int d = 0; d < 5; d++) { rlo[d] = lhi[d]; rhi[d] = llo[d]; }
+#else
     mvdr_frame_pairs(stage32, lane, mvdr_load_block(right, n_blocks, st_in->prev_r, jp, lane),
                      mvdr_load_block(right, n_blocks, st_in->prev_r, j, lane), v, 0.5f);
     wave_fft512<false>(v, lds, lane, tw);
@@ -457,11 +469,17 @@ __global__ __launch_bounds__(64) void mvdr_pairs_kernel(const short *__restrict_
         rlo[d] = cadd(e, t);
         rhi[d] = csub(e, t);
     }
-    // the matrix in effect at this block
+#endif
+    // the matrix in effect at this block (looking it up ahead of the transforms instead measured the same)
+#if JDSP_MVDR_ABLATE == 4                                   // timing only: no version lookup
+    int ver = 0;
+    const bool tabled = true;
+#else
     int ver = version_of(ver_base, snap_mask, j + sh.ver_block_off);
     if (sh.ver_row_off) ver -= *sh.ver_row_off;
     if (ver < 0) ver = 0;
     const bool tabled = wtab && plan->n_events < kMvdrTableVersions;       // wave-uniform
+#endif
     const float4 *wrow = wtab + (size_t)ver * 1024;
     MvdrInv iv = {0.0, 0.0, 0.0, 0.0};
     if (!tabled) iv = mvdr_inverse(rver + (size_t)ver * 4);
@@ -471,7 +489,11 @@ __global__ __launch_bounds__(64) void mvdr_pairs_kernel(const short *__restrict_
         const int m = lane + 64 * d;
         const int b1 = (1024 - m) & 1023, b3 = 512 - m;
         float4 w0, w1, w2, w3;
+#if JDSP_MVDR_ABLATE == 1                                   // timing only: no table loads
+        if (tabled) { w0 = w1 = w2 = w3 = make_float4(0.5f, 0.25f, 0.5f, -0.25f); }
+#else
         if (tabled) { w0 = wrow[m]; w1 = wrow[b1]; w2 = wrow[m + 512]; w3 = wrow[b3]; }
+#endif
         else {
             w0 = mvdr_bin_weights(iv, steer[m]); w1 = mvdr_bin_weights(iv, steer[b1]);
             w2 = mvdr_bin_weights(iv, steer[m + 512]); w3 = mvdr_bin_weights(iv, steer[b3]);
