@@ -238,14 +238,19 @@ __device__ __forceinline__ void mvdr_frame_pairs(unsigned int *stage32, int lane
     reinterpret_cast<u32x4 *>(stage32)[64 + lane] = img_cur;
     if (lane == 0) stage32[512] = 0u;
     wave_lds_fence();
+    // position p = 2 lane + 128 r: r < 3 lies below 510 for every lane, r = 3 reaches 510 in lane 63 only, r > 3 lies
+    // above (and the pair at 1022 ends in the zero of stage32[512])
 #pragma unroll
     for (int r = 0; r < 8; r++) {
-        const int p = 2 * lane + 128 * r;
-        const unsigned int a = stage32[p >> 1], b = stage32[(p >> 1) + 1];
+        const int i = lane + 64 * r;
+        const unsigned int a = stage32[i];
         float x0, x1;
-        if (p < 510) { x0 = (float)(short)(a & 0xffffu); x1 = (float)((int)a >> 16); }
-        else if (p == 510) { x0 = (float)(short)(a & 0xffffu); x1 = (float)(short)(b & 0xffffu); }
-        else { x0 = (float)((int)a >> 16); x1 = p == 1022 ? 0.f : (float)(short)(b & 0xffffu); }
+        if (r < 3) { x0 = (float)(short)(a & 0xffffu); x1 = (float)((int)a >> 16); }
+        else {
+            const unsigned int b = stage32[i + 1];
+            if (r == 3) { x0 = (float)(short)(a & 0xffffu); x1 = lane == 63 ? (float)(short)(b & 0xffffu) : (float)((int)a >> 16); }
+            else { x0 = (float)((int)a >> 16); x1 = (float)(short)(b & 0xffffu); }
+        }
         v[r] = make_float2(scale * x0, scale * x1);
     }
     wave_lds_fence();
