@@ -156,7 +156,7 @@ def test_mvdrn_cfg_rejects_other_frame_lengths(eng):
 
 @pytest.mark.parametrize("n_fft", [1024, 512])
 def test_many_estimation_frames_per_call(eng, oracle, n_fft):
-    """More events than the covariance update has chunks (32): several events per chunk, chunk sums, the prefix over
+    """More events than the covariance update has chunks (128): several events per chunk, chunk sums, the prefix over
     chunks and the per-chunk walks all in play; the weights of every version are used by some block."""
     block = n_fft // 2
     n_blocks = 260
@@ -172,9 +172,10 @@ def test_many_estimation_frames_per_call(eng, oracle, n_fft):
     m.close()
 
 
-@pytest.mark.parametrize("n_quiet", [31, 32, 33, 34, 65])
+@pytest.mark.parametrize("n_quiet", [31, 33, 65, 127, 128, 129, 130, 257, 258])
 def test_covariance_chunk_geometry_edges(eng, oracle, n_quiet):
-    """Event counts on both sides of the chunked update's boundary (32 chunks: one event per chunk up to 32, two from 33)."""
+    """Event counts on both sides of the chunked update's boundaries (128 chunks: one event per chunk up to 128, two from
+    129, three from 257; a run of n quiet blocks is n - 1 or n events)."""
     n_blocks = n_quiet + 12
     pcm, _, delays = array_scene(70 + n_quiet, 3, n_blocks, quiet=((4, n_quiet),))
     o_out, o_pre = oracle.mvdrn_stream(pcm, delays, 1e-3)
