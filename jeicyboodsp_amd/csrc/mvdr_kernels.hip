@@ -6,7 +6,7 @@
 //
 //   vad_kernel (denoise_kernels.hip)   :207-242 energy-only decision, window offset 511
 //   plan_kernel (denoise_kernels.hip)  main()'s run counter :191-219; every event changes R
-//   mvdr_corr_kernel                   :244-270 per event: the four sums over 1024 bins
+//   mvdr_corr_kernel                   :244-270 per event: the four sums over 1024 bins (by Parseval: two energies)
 //   mvdr_prefix_kernel                 running R after each event (FP64)
 //   mvdr_kernel                        :124-205 one block per wavefront
 #include "frame_io.h"
@@ -62,57 +62,44 @@ __device__ __forceinline__ double wave_sum_f64(double v)
     return v;
 }
 
-// :244-270 -- frame = [block j-1, block j] of each channel, no window
+// :244-270 -- frame = [block j-1, block j] of each channel, no window, through two FP64 transforms, then over ALL 1024 bins
+//   R[0][0] += |L_k|^2 / N,   R[0][1] += (-Re L_k Im R_k + Im L_k Re R_k) / N,   R[1][0] likewise,   R[1][1] += |R_k|^2 / N.
+// The frames are real, so the spectra are Hermitian: the cross terms of bins k and N - k are each other's negatives (and
+// those of bins 0 and N / 2 are zero) -- the reference's R[0][1], R[1][0] receive nothing but its transform's rounding,
+// 1e-17 of R[0][0] -- and by Parseval sum_k |L_k|^2 / N = sum_n l_n^2, an integer below 2^41.  So an event's contribution
+// is (sum l^2, 0, 0, sum r^2), exact, with no transform: it agrees with the FP64 restatement of the reference to 1e-15
+// (tests/test_mvdr_gpu.py) where two FP32 transforms per event agreed to 1e-7 and cost 182 us per 65,536 events.
+__device__ __forceinline__ unsigned long long sum_squares_i16x8(u32x4 w)
+{
+    unsigned long long acc = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int a = (short)(w[q] & 0xffffu), b = (int)w[q] >> 16;
+        acc += (unsigned int)(a * a) + (unsigned int)(b * b);             // <= 2^31: fits
+    }
+    return acc;
+}
+
 __global__ __launch_bounds__(64) void mvdr_corr_kernel(const short *__restrict__ left, const short *__restrict__ right,
                                                        long n_blocks, const MvdrState *__restrict__ st_in,
                                                        const int *__restrict__ events,
                                                        const DenoisePlan *__restrict__ plan,
-                                                       const float2 *__restrict__ table, double *__restrict__ delta,
+                                                       double *__restrict__ delta,
                                                        const int *__restrict__ range, long ext0)
 {
     // range (device, or NULL: every event) = {first, one past last} event this launch handles;
     // ext0 = global index of the first block the pcm pointers hold (sharded runs)
-    __shared__ __attribute__((aligned(16))) float2 lds[kWaveLdsComplex];
-    __shared__ __attribute__((aligned(16))) unsigned int stage[256];
     const int lane = threadIdx.x;
     const int e_lo = range ? range[0] : 0, e_hi = range ? range[1] : plan->n_events;
-    if (e_lo + (int)blockIdx.x >= e_hi) return;
-    WaveTwiddles tw;
-    load_wave_twiddles(tw, table, lane);
-    const float2 wsp[2] = {table[kStftSplit + 2 * lane], table[kStftSplit + 2 * lane + 1]};
     for (int e = e_lo + blockIdx.x; e < e_hi; e += gridDim.x) {
         const long j = events[e] - ext0;
-        float2 llo[8], lhi[8], rlo[8], rhi[8], v[8];
-        unsigned int raw[8];
-        relayout_half(stage, lane, mvdr_load_block(left, n_blocks, st_in->prev_l, j - 1, lane), raw);
-        relayout_half(stage, lane, mvdr_load_block(left, n_blocks, st_in->prev_l, j, lane), raw + 4);
-#pragma unroll
-        for (int r = 0; r < 8; r++) { const float2 s = unpack_i16x2(raw[r]); v[r] = make_float2(0.5f * s.x, 0.5f * s.y); }
-        spectrum_of(v, lds, lane, tw, wsp, llo, lhi);
-        relayout_half(stage, lane, mvdr_load_block(right, n_blocks, st_in->prev_r, j - 1, lane), raw);
-        relayout_half(stage, lane, mvdr_load_block(right, n_blocks, st_in->prev_r, j, lane), raw + 4);
-#pragma unroll
-        for (int r = 0; r < 8; r++) { const float2 s = unpack_i16x2(raw[r]); v[r] = make_float2(0.5f * s.x, 0.5f * s.y); }
-        spectrum_of(v, lds, lane, tw, wsp, rlo, rhi);
-        double s00 = 0, s01 = 0, s10 = 0, s11 = 0;
-#pragma unroll
-        for (int q = 0; q < 8; q++) {
-#pragma unroll
-            for (int h = 0; h < 2; h++) {
-                const float2 L = h ? lhi[q] : llo[q], R = h ? rhi[q] : rlo[q];
-                s00 += (double)(L.x * L.x + L.y * L.y);                 // :264
-                s01 += (double)(-L.x * R.y + L.y * R.x);                // :265
-                s10 += (double)(-R.x * L.y + R.y * L.x);                // :266
-                s11 += (double)(R.x * R.x + R.y * R.y);                 // :267
-            }
-        }
-        // wave sums by DPP moves (lane 63 ends up with the total): a __shfl_xor tree is 48 ds_bpermute here, 8.9 issue
-        // slots each -- and an all-quiet stream runs this once per block
-        s00 = wave_sum_f64(s00); s01 = wave_sum_f64(s01); s10 = wave_sum_f64(s10); s11 = wave_sum_f64(s11);
-        if (lane == 63) {
-            double *d = delta + (size_t)(e - e_lo) * 4;
-            d[0] = s00 / 1024.0; d[1] = s01 / 1024.0; d[2] = s10 / 1024.0; d[3] = s11 / 1024.0;
-        }
+        const unsigned long long el = sum_squares_i16x8(mvdr_load_block(left, n_blocks, st_in->prev_l, j - 1, lane)) +
+                                      sum_squares_i16x8(mvdr_load_block(left, n_blocks, st_in->prev_l, j, lane));
+        const unsigned long long er = sum_squares_i16x8(mvdr_load_block(right, n_blocks, st_in->prev_r, j - 1, lane)) +
+                                      sum_squares_i16x8(mvdr_load_block(right, n_blocks, st_in->prev_r, j, lane));
+        // wave sums by DPP moves (lane 63 ends up with the total); integers below 2^41: exact in FP64
+        const double s00 = wave_sum_f64((double)el), s11 = wave_sum_f64((double)er);
+        if (lane == 63) *reinterpret_cast<double4 *>(delta + (size_t)(e - e_lo) * 4) = make_double4(s00, 0.0, 0.0, s11);
     }
 }
 
@@ -549,7 +536,7 @@ int launch_mvdr(hipStream_t s, const short *left, const short *right, long n_blo
     if (n_blocks <= 0) return 0;
     const long g1 = n_blocks < 2048 ? n_blocks : 2048;
     hipLaunchKernelGGL(mvdr_corr_kernel, dim3((unsigned)g1), dim3(64), 0, s, left, right, n_blocks, st_in, events, plan,
-                       table, delta, (const int *)nullptr, 0L);
+                       delta, (const int *)nullptr, 0L);
     launch_mvdr_prefix(s, delta, plan, nullptr, st_in->corr, nullptr, 0, st_out, rver, nullptr, tile_sums);
     DenoiseShard sh;
     sh.ver_block_off = 0;
@@ -578,7 +565,7 @@ int launch_mvdr_corr_total(hipStream_t s, const short *left, const short *right,
     if (n_blocks <= 0) return 0;
     const long g1 = n_blocks < 2048 ? n_blocks : 2048;
     hipLaunchKernelGGL(mvdr_corr_kernel, dim3((unsigned)g1), dim3(64), 0, s, left, right, n_blocks, st_in, events, plan,
-                       table, delta, (const int *)nullptr, 0L);
+                       delta, (const int *)nullptr, 0L);
     launch_mvdr_prefix(s, delta, plan, nullptr, nullptr, nullptr, 0, nullptr, nullptr, total, tile_sums);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
@@ -626,7 +613,7 @@ int launch_mvdr_shard_summary(hipStream_t s, const short *left_ext, const short 
     const long own = b1 - b0;
     const long g1 = own < 2048 ? (own > 0 ? own : 1) : 2048;
     hipLaunchKernelGGL(mvdr_corr_kernel, dim3((unsigned)g1), dim3(64), 0, s, left_ext, right_ext, n_ext, zero_state, events,
-                       plan, table, delta, (const int *)range, ext0);
+                       plan, delta, (const int *)range, ext0);
     launch_mvdr_prefix(s, delta, plan, range, nullptr, nullptr, 0, nullptr, nullptr, total, tile_sums);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }

@@ -171,6 +171,25 @@ def test_pause_heavy_stream_uses_the_parallel_prefix(eng, oracle):
     m.close()
 
 
+def test_running_matrix_agrees_with_the_fp64_restatement_to_1e12(eng, oracle):
+    """EstimateSpatialCorrMtx's sums over the 1024 bins of two real frames are, by Parseval and the Hermitian symmetry of
+    the spectra, (sum l^2, 0, 0, sum r^2): the device adds those integers.  The restatement of the reference's
+    own arithmetic (FP64 transforms, :244-270) must then agree to FP64 rounding -- over a stream, a handful of events and
+    thousands -- and its cross terms must be nothing but that rounding."""
+    for nb, quiet in ((64, ((0, 8), (20, 5), (40, 12))), (3000, tuple((b0, 19) for b0 in range(0, 2975, 24)))):
+        L, R = stereo(91 + nb, nb, quiet=quiet)
+        _, _, o_corr, _ = oracle.mvdr_stream(L, R, 0.0)
+        m = eng.mvdr(0.0)
+        m.process(L, R)
+        c = m.corr()
+        m.close()
+        scale = max(o_corr[0], o_corr[3])
+        assert scale > 1e6
+        assert abs(c[0] - o_corr[0]) <= 1e-12 * scale and abs(c[3] - o_corr[3]) <= 1e-12 * scale
+        assert c[1] == 0.0 and c[2] == 0.0
+        assert abs(o_corr[1]) <= 1e-12 * scale and abs(o_corr[2]) <= 1e-12 * scale
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_mvdr_sharded_pause_heavy(eng, oracle, world):
     """Sharded run whose ranks each hold more than a tile (1,024) of estimation events: the tiled prefix with a rank's
