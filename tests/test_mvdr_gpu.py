@@ -156,8 +156,8 @@ def test_estimate_and_apply_on_their_own_in_any_order(eng, oracle):
 
 
 def test_pause_heavy_stream_uses_the_parallel_prefix(eng, oracle):
-    """Thousands of EstimateSpatialCorrMtx events in one call: the running matrix comes from the 1,024-thread scan
-    (several events per thread), not from the four-thread walk of short event lists."""
+    """Thousands of EstimateSpatialCorrMtx events in one call: the running matrix comes from the tiled scan (1,024 events
+    per workgroup, then the tiles' bases), not from the four-thread walk of short event lists."""
     nb = 3000
     quiet = tuple((b0, 19) for b0 in range(0, nb - 25, 24))             # ~2,300 quiet blocks
     L, R = stereo(33, nb, quiet=quiet)
