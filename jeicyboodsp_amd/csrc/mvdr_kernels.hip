@@ -354,6 +354,9 @@ __global__ __launch_bounds__(64) void mvdr_kernel(const short *__restrict__ left
 #ifndef JDSP_MVDR_PAIRS
 #define JDSP_MVDR_PAIRS 1
 #endif
+#ifndef JDSP_MVDR_EARLY_LOADS
+#define JDSP_MVDR_EARLY_LOADS 1
+#endif
 #ifndef JDSP_MVDR_ABLATE
 #define JDSP_MVDR_ABLATE 0      // 1..4: timing-only builds that drop one part of mvdr_pairs_kernel (tools/build_variant.sh)
 #endif
@@ -428,6 +431,11 @@ __global__ __launch_bounds__(64) void mvdr_pairs_kernel(const short *__restrict_
     const long jp = have_prev ? j - 1 : -2;          // keep buffer of a stream's very first block: zeros (:130-131)
 
     float2 llo[5], lhi[5], rlo[5], rhi[5], v[8], zr[5];
+#if JDSP_MVDR_EARLY_LOADS
+    // the right channel's blocks are requested before the left channel's transform (whose LDS fences would hold the loads back)
+    const u32x4 r_prev = mvdr_load_block(right, n_blocks, st_in->prev_r, jp, lane);
+    const u32x4 r_cur = mvdr_load_block(right, n_blocks, st_in->prev_r, j, lane);
+#endif
     mvdr_frame_pairs(stage32, lane, mvdr_load_block(left, n_blocks, st_in->prev_l, jp, lane),
                      mvdr_load_block(left, n_blocks, st_in->prev_l, j, lane), v, 0.5f);
     wave_fft512<false>(v, lds, lane, tw);
@@ -444,8 +452,12 @@ __global__ __launch_bounds__(64) void mvdr_pairs_kernel(const short *__restrict_
 #pragma unroll
     for (int d = 0; d < 5; d++) { rlo[d] = lhi[d]; rhi[d] = llo[d]; }
 #else
+#if JDSP_MVDR_EARLY_LOADS
+    mvdr_frame_pairs(stage32, lane, r_prev, r_cur, v, 0.5f);
+#else
     mvdr_frame_pairs(stage32, lane, mvdr_load_block(right, n_blocks, st_in->prev_r, jp, lane),
                      mvdr_load_block(right, n_blocks, st_in->prev_r, j, lane), v, 0.5f);
+#endif
     wave_fft512<false>(v, lds, lane, tw);
     wave_lds_fence();
     pair_fetch_lds(v, lds, lane, zr);

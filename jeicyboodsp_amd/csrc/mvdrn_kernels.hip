@@ -397,16 +397,22 @@ __global__ __launch_bounds__(64) void mvdrn_apply_pairs_kernel(const short *__re
     float2 ylo[5], yhi[5];
 #pragma unroll
     for (int d = 0; d < 5; d++) { ylo[d] = make_float2(0.f, 0.f); yhi[d] = make_float2(0.f, 0.f); }
+    // a microphone's two blocks are requested while the one before it is transformed (the LDS fences would hold the loads back)
+    const long jp = have_prev ? j - 1 : -2;
+    u32x4 nxt_prev = mvn_block(pcm, n_blocks, prev_in, jp, lane), nxt_cur = mvn_block(pcm, n_blocks, prev_in, j, lane);
     for (int m = 0; m < n_mics; m++) {
         const short *chan = pcm + (size_t)m * chan_stride;
-        const short *prev = prev_in + (size_t)m * 512;
         const float2 *Wm = W + (size_t)m * kMvnBins;
         float2 wl[5], wh[5];
 #pragma unroll
         for (int d = 0; d < 5; d++) { wl[d] = Wm[lane + 64 * d]; wh[d] = Wm[512 - lane - 64 * d]; }
+        const u32x4 img_prev = nxt_prev, img_cur = nxt_cur;
+        if (m + 1 < n_mics) {
+            nxt_prev = mvn_block(chan + chan_stride, n_blocks, prev_in + (size_t)(m + 1) * 512, jp, lane);
+            nxt_cur = mvn_block(chan + chan_stride, n_blocks, prev_in + (size_t)(m + 1) * 512, j, lane);
+        }
         float2 v[8], zr[5];
-        mvdr_frame_pairs(stage32, lane, mvn_block(chan, n_blocks, prev, have_prev ? j - 1 : -2, lane),
-                         mvn_block(chan, n_blocks, prev, j, lane), v, 0.5f);
+        mvdr_frame_pairs(stage32, lane, img_prev, img_cur, v, 0.5f);
         wave_fft512<false>(v, lds, lane, tw);
         wave_lds_fence();
         pair_fetch_lds(v, lds, lane, zr);
