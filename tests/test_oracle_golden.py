@@ -270,3 +270,21 @@ def test_mfcc_stream(oracle):
     # generic frames API agrees with the stream API
     fr = oracle.mfcc_frames(cfg, np.concatenate([np.zeros(512, np.int16), pcm]), 2 * nb - 1, first_frame=1)
     assert np.array_equal(fr, feats)
+
+
+def test_mvdr_estimate_is_the_two_frame_energies(oracle):
+    """EstimateSpatialCorrMtx (BF:244-270) sums |L_k|^2 / N, |R_k|^2 / N and the cross terms -Re L Im R + Im L Re R over
+    all 1024 bins of two REAL frames.  The cross terms of bins k and N - k cancel and Parseval turns the others into
+    sum l^2, sum r^2 -- which is what the device kernel adds (mvdr_corr_kernel).  The restatement of the reference's own
+    arithmetic (FP64 transforms) must say so to FP64 rounding, also for full-scale and for silent frames."""
+    rng = np.random.default_rng(12)
+    for scale in (40, 3000, 32767):
+        l = np.clip(np.rint(rng.normal(0, scale, 1024)), -32768, 32767).astype(np.int16)
+        r = np.clip(np.rint(rng.normal(0, scale / 2, 1024)), -32768, 32767).astype(np.int16)
+        c = oracle.mvdr_estimate(l, r, np.zeros(4))
+        el, er = int((l.astype(np.int64) ** 2).sum()), int((r.astype(np.int64) ** 2).sum())
+        assert abs(c[0] - el) <= 1e-12 * el and abs(c[3] - er) <= 1e-12 * er
+        assert abs(c[1]) <= 1e-12 * el and abs(c[2]) <= 1e-12 * el
+    full = np.full(1024, -32768, np.int16)
+    c = oracle.mvdr_estimate(full, np.zeros(1024, np.int16), np.array([1.0, 2.0, 3.0, 4.0]))
+    assert abs(c[0] - (1.0 + 1024 * 2.0 ** 30)) <= 1e-3 and c[3] == 4.0      # added to the caller's matrix; 2^40 fits FP64 exactly
