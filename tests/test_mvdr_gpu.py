@@ -145,6 +145,11 @@ def test_estimate_and_apply_on_their_own_in_any_order(eng, oracle):
     assert np.abs(got - corr).max() > 1e3                                     # something was added
     one = m.estimate_corr(frames_l[0], frames_r[0], np.zeros(4))
     assert np.abs(one - oracle.mvdr_estimate(frames_l[0], frames_r[0], np.zeros(4))).max() <= TOL * np.abs(one).max()
+    # the sums are integers (two frame energies): full-scale frames, the largest they get, come out exactly
+    fs_l = np.full((3, 1024), -32768, np.int16)
+    fs_r = np.full((3, 1024), 32767, np.int16)
+    fs = m.estimate_corr(fs_l, fs_r, np.zeros(4))
+    assert fs[0] == 3 * 1024 * 2.0 ** 30 and fs[3] == 3 * 1024 * 32767.0 ** 2 and fs[1] == 0.0 and fs[2] == 0.0
     # the stream continues (keep buffers carried) with the new matrix
     out2, pre2 = m.apply(L[5 * 512:9 * 512], R[5 * 512:9 * 512], got, want_precast=True)
     st_out, st_pre = oracle.mvdr_apply(L[4 * 512:9 * 512], R[4 * 512:9 * 512], want, 2.5e-4)    # block 4 primes the keep buffers
