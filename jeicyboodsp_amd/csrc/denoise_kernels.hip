@@ -390,6 +390,9 @@ __device__ __forceinline__ ChunkGeom chunk_geom(int n_events, int grid)
     return g;
 }
 
+#ifndef JDSP_ACCUM_PAIRS
+#define JDSP_ACCUM_PAIRS 1
+#endif
 __global__ __launch_bounds__(64) void noise_accum_kernel(const short *__restrict__ pcm, long n_blocks,
                                                          const DenoiseState *__restrict__ st_in,
                                                          const int *__restrict__ events, const int *__restrict__ ev_n,
@@ -413,18 +416,40 @@ __global__ __launch_bounds__(64) void noise_accum_kernel(const short *__restrict
     const int e1 = e0 + cg.per_chunk < n_events ? e0 + cg.per_chunk : n_events;
     FrameTables t;
     load_frame_tables(t, table, lane);
+#if JDSP_ACCUM_PAIRS
+    // Pair-owned bins (frame_io.h): |X| of the bins m, m + 512 of m = lane + 64 d, d < 5; the bins 1024 - m and 512 - m
+    // are their mirrors (a real frame), so ten magnitudes per lane and event instead of sixteen.  A row is stored as the
+    // ten own values plus the mirrors of m = 1..192 (the items of d = 3, 4 mirror each other: those bins are stored by
+    // their owners only).
+    PairTwiddles pw;
+    load_pair_twiddles(pw, table, lane);
+    constexpr int ND = 5;
+#else
     SplitTwiddles sw;
     load_split_twiddles(sw, table, lane);
-    float blo[8], bhi[8], alpha = 1.0f;                          // beta[lane + 64 d], beta[lane + 64 d + 512]
+    constexpr int ND = 8;
+#endif
+    float blo[ND], bhi[ND], alpha = 1.0f;                        // beta[lane + 64 d], beta[lane + 64 d + 512]
+    auto store_row = [&](float *row) {
 #pragma unroll
-    for (int d = 0; d < 8; d++) blo[d] = bhi[d] = 0.0f;
+        for (int d = 0; d < ND; d++) { row[lane + 64 * d] = blo[d]; row[lane + 64 * d + 512] = bhi[d]; }
+#if JDSP_ACCUM_PAIRS
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+            const int m = lane + 64 * d;
+            if (m >= 1 && m <= 192) { row[1024 - m] = blo[d]; row[512 - m] = bhi[d]; }
+        }
+#endif
+    };
+#pragma unroll
+    for (int d = 0; d < ND; d++) blo[d] = bhi[d] = 0.0f;
     for (int e = e0; e < e1; e++) {
         const long jg = events[e_base + e], j = jg - ext0;
         const int n = ev_n[e_base + e];
         unsigned int prev[4], cur[4];
         load_block_pairs(pcm, n_blocks, st_in, j - 1, lane, prev);   // rgssKeepBuffer (SS:165-170)
         load_block_pairs(pcm, n_blocks, st_in, j, lane, cur);
-        float2 v[8], zr[8], lo[8], hi[8];
+        float2 v[8], zr[ND], lo[ND], hi[ND];
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const float2 s0 = unpack_i16x2(prev[r]), s1 = unpack_i16x2(cur[r]);
@@ -433,11 +458,22 @@ __global__ __launch_bounds__(64) void noise_accum_kernel(const short *__restrict
         }
         wave_fft512<false>(v, lds, lane, t.tw);
         wave_lds_fence();
+#if JDSP_ACCUM_PAIRS
+        pair_fetch_lds(v, lds, lane, zr);
+#pragma unroll
+        for (int d = 0; d < ND; d++) {
+            const float2 ev = cadd_conj(v[d], zr[d]), od = csub_conj_mj(v[d], zr[d]);
+            const float2 tw = cmul(pw.w[d], od);
+            lo[d] = cadd(ev, tw);
+            hi[d] = csub(ev, tw);
+        }
+#else
         mirror_fetch_lds(v, lds, lane, zr);
         split_fwd_reg(v, zr, sw, lo, hi);
+#endif
         const float h = n >= 3 ? 0.5f : 1.0f;                    // SS:182-187
 #pragma unroll
-        for (int d = 0; d < 8; d++) {
+        for (int d = 0; d < ND; d++) {
             // hardware square root (1 ulp; sqrtf() expands to ~12 instructions of scaling and fix-up per value, a third
             // of this loop)
             blo[d] = (blo[d] + __builtin_amdgcn_sqrtf(lo[d].x * lo[d].x + lo[d].y * lo[d].y)) * h;
@@ -446,15 +482,11 @@ __global__ __launch_bounds__(64) void noise_accum_kernel(const short *__restrict
         alpha *= h;
         if (n == latch_run) {                                    // SS:189-193
             const int row = version_of(ver_base, snap_mask, jg) - row_off;
-            float *dst = noise_rows + (size_t)row * 1024 + lane;
-#pragma unroll
-            for (int d = 0; d < 8; d++) { dst[64 * d] = blo[d]; dst[64 * d + 512] = bhi[d]; }
+            store_row(noise_rows + (size_t)row * 1024);
             if (lane == 0) { acc.lat_alpha[row] = alpha; acc.lat_chunk[row] = chunk; }
         }
     }
-    float *dst = acc.chunk_beta + (size_t)chunk * 1024 + lane;
-#pragma unroll
-    for (int d = 0; d < 8; d++) { dst[64 * d] = blo[d]; dst[64 * d + 512] = bhi[d]; }
+    store_row(acc.chunk_beta + (size_t)chunk * 1024);
     if (lane == 0) acc.chunk_alpha[chunk] = alpha;
 }
 
