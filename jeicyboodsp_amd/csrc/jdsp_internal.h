@@ -73,7 +73,7 @@ struct DenoiseShard {
 };
 
 // BeamForming_MVDR_ver1.cpp's state between calls (device memory)
-constexpr int kMvdrTableVersions = 1024;     // 2-microphone MVDR: calls with fewer events than this get their weights from a table
+constexpr int kMvdrTableVersions = 8192;     // 2-microphone MVDR: calls with fewer events than this get their weights from a table (16 KB per version)
 constexpr int kMvnChunks = 128;            // chunks the n-microphone covariance update cuts a call's events into
 
 struct MvdrState {
@@ -341,7 +341,7 @@ struct jdsp_mvdr {
     unsigned long long *snap_mask = nullptr;
     double *delta = nullptr, *rver = nullptr;
     double *tile_sums = nullptr;          // [cap_blocks / 1024 + 1][4] sums of the prefix pass's tiles of 1024 events
-    float4 *wtab = nullptr;               // [kMvdrTableVersions][1024] per-version weights (mvdr_weights_kernel)
+    float4 *wtab = nullptr;               // [min(cap_blocks + 1, kMvdrTableVersions)][1024] per-version weights (mvdr_weights_kernel)
     // sharded (multi-GPU) run in progress
     long sh_ext0 = 0, sh_b0 = 0, sh_b1 = 0, sh_total = 0;
     const int16_t *sh_left = nullptr, *sh_right = nullptr;

@@ -5,13 +5,14 @@ using jdsp::fail;
 
 static void mvdr_free_ws(jdsp_mvdr *h)
 {
-    void *p[] = {h->flags, h->events, h->ev_n, h->ver_base, h->snap_mask, h->delta, h->rver, h->tile_sums};
+    void *p[] = {h->flags, h->events, h->ev_n, h->ver_base, h->snap_mask, h->delta, h->rver, h->tile_sums, h->wtab};
     for (void *q : p)
         if (q) (void)hipFree(q);
     h->flags = nullptr;
     h->events = h->ev_n = h->ver_base = nullptr;
     h->snap_mask = nullptr;
     h->delta = h->rver = h->tile_sums = nullptr;
+    h->wtab = nullptr;
     h->cap_blocks = 0;
 }
 
@@ -39,7 +40,6 @@ int jdsp_mvdr_create(jdsp_ctx *ctx, double d_time, jdsp_mvdr **out)
     for (int i = 0; i < 2 && e == hipSuccess; i++) e = hipMalloc((void **)&h->st[i], sizeof(jdsp::MvdrState));
     if (e == hipSuccess) e = hipMalloc((void **)&h->plan, sizeof(jdsp::DenoisePlan));
     if (e == hipSuccess) e = hipMalloc((void **)&h->steer, sizeof(double2) * 1024);
-    if (e == hipSuccess) e = hipMalloc((void **)&h->wtab, sizeof(float4) * (size_t)jdsp::kMvdrTableVersions * 1024);
     if (e == hipSuccess) e = hipMalloc((void **)&h->w_vad, sizeof(w));
     if (e == hipSuccess) e = hipMalloc((void **)&h->sh_range, 4 * sizeof(int));
     if (e == hipSuccess) e = hipMalloc((void **)&h->sh_zero_run, sizeof(int));
@@ -69,7 +69,6 @@ int jdsp_mvdr_destroy(jdsp_mvdr *h)
         if (h->st[i]) (void)hipFree(h->st[i]);
     if (h->plan) (void)hipFree(h->plan);
     if (h->steer) (void)hipFree(h->steer);
-    if (h->wtab) (void)hipFree(h->wtab);
     if (h->w_vad) (void)hipFree(h->w_vad);
     if (h->sh_range) (void)hipFree(h->sh_range);
     if (h->sh_zero_run) (void)hipFree(h->sh_zero_run);
@@ -108,6 +107,9 @@ static int mvdr_reserve(jdsp_mvdr *h, long n_blocks)
     if (e == hipSuccess) e = hipMalloc((void **)&h->delta, n * 4 * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void **)&h->rver, (n + 1) * 4 * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void **)&h->tile_sums, (n / 1024 + 1) * 4 * sizeof(double));
+    // a call has at most as many events as blocks: the weight table needs no more rows than that
+    const size_t wrows = n + 1 < (size_t)jdsp::kMvdrTableVersions ? n + 1 : (size_t)jdsp::kMvdrTableVersions;
+    if (e == hipSuccess) e = hipMalloc((void **)&h->wtab, sizeof(float4) * wrows * 1024);
     if (e != hipSuccess) {
         mvdr_free_ws(h);
         return fail(ctx, JDSP_ENOMEM, "jdsp_mvdr: workspace", e);

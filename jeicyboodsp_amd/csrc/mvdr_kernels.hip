@@ -400,11 +400,12 @@ __device__ __forceinline__ float2 mvdr_apply_weights(float4 w, float2 L, float2 
 __global__ __launch_bounds__(256) void mvdr_weights_kernel(const DenoisePlan *__restrict__ plan, const double *__restrict__ rver,
                                                            const double2 *__restrict__ steer, float4 *__restrict__ wtab)
 {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    const int ver = idx >> 10, bin = idx & 1023;
     const int n_events = plan->n_events;
-    if (n_events >= kMvdrTableVersions || ver > n_events) return;          // too many versions: the block kernel computes
-    wtab[idx] = mvdr_bin_weights(mvdr_inverse(rver + (size_t)ver * 4), steer[bin]);
+    if (n_events >= kMvdrTableVersions) return;                            // too many versions: the block kernel computes
+    const int bin = threadIdx.x + 256 * (blockIdx.x & 3);
+    const double2 s1 = steer[bin];
+    for (int ver = blockIdx.x >> 2; ver <= n_events; ver += gridDim.x >> 2)
+        wtab[(size_t)ver * 1024 + bin] = mvdr_bin_weights(mvdr_inverse(rver + (size_t)ver * 4), s1);
 }
 
 __global__ __launch_bounds__(64) void mvdr_pairs_kernel(const short *__restrict__ left, const short *__restrict__ right,
@@ -557,8 +558,8 @@ int launch_mvdr(hipStream_t s, const short *left, const short *right, long n_blo
     sh.emit_to = n_blocks;
     const long grid = (n_blocks + 7) / 8 * 8;
 #if JDSP_MVDR_PAIRS
-    if (wtab)                                            // wtab: kMvdrTableVersions x 1024 float4, or NULL (no table)
-        hipLaunchKernelGGL(mvdr_weights_kernel, dim3(kMvdrTableVersions * 1024 / 256), dim3(256), 0, s, plan, rver, steer, wtab);
+    if (wtab)                                            // wtab: min(blocks + 1, kMvdrTableVersions) x 1024 float4, or NULL (no table)
+        hipLaunchKernelGGL(mvdr_weights_kernel, dim3(4096), dim3(256), 0, s, plan, rver, steer, wtab);     // 1,024 versions per pass
     hipLaunchKernelGGL(mvdr_pairs_kernel, dim3((unsigned)grid), dim3(64), 0, s, left, right, n_blocks, calls_before, st_in,
                        st_out, ver_base, snap_mask, rver, steer, table, out, precast, sh, plan, (const float4 *)wtab);
 #else

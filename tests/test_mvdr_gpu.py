@@ -225,10 +225,11 @@ def test_mvdr_sharded_pause_heavy(eng, oracle, world):
     assert np.abs(got.astype(np.int32) - o_out.astype(np.int32)).max() <= 1
 
 
-@pytest.mark.parametrize("n_quiet", [1021, 1024, 1027])
+@pytest.mark.parametrize("n_quiet", [1027, 8189, 8192, 8195])
 def test_weight_table_boundary(eng, oracle, n_quiet):
-    """Calls with fewer than 1,024 events read their per-bin weights from the per-version table, calls with more compute
-    them per block: both sides of that boundary against the oracle (one quiet run of n blocks = n - 1 or n events)."""
+    """Calls with fewer than 8,192 events read their per-bin weights from the per-version table (filled 1,024 versions per
+    pass), calls with more compute them per block: both sides of that boundary against the oracle (one quiet run of n
+    blocks = n - 1 or n events)."""
     nb = n_quiet + 40
     L, R = stereo(50 + n_quiet, nb, quiet=((20, n_quiet),))
     o_out, o_pre, o_corr, trace = oracle.mvdr_stream(L, R, 2.5e-4)
