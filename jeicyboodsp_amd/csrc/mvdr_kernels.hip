@@ -397,11 +397,20 @@ __device__ __forceinline__ float2 mvdr_apply_weights(float4 w, float2 L, float2 
     return make_float2(L.x + Rr.x, L.y + Rr.y);
 }
 
+// Weights from the table or computed per block?  A version's row costs 1,024 evaluations and 16 KB written and read
+// back; computing costs 1,280 evaluations per block.  The table wins while versions are few against blocks (under a
+// quarter here) or few outright (under 1,024: the rows stay in L2).
+__device__ __forceinline__ bool mvdr_tabled(int n_events, long n_blocks)
+{
+    return n_events < 1024 || (n_events < kMvdrTableVersions && 4L * n_events < n_blocks);
+}
+
 __global__ __launch_bounds__(256) void mvdr_weights_kernel(const DenoisePlan *__restrict__ plan, const double *__restrict__ rver,
-                                                           const double2 *__restrict__ steer, float4 *__restrict__ wtab)
+                                                           const double2 *__restrict__ steer, float4 *__restrict__ wtab,
+                                                           long n_blocks)
 {
     const int n_events = plan->n_events;
-    if (n_events >= kMvdrTableVersions) return;                            // too many versions: the block kernel computes
+    if (!mvdr_tabled(n_events, n_blocks)) return;                          // the block kernel computes its own
     const int bin = threadIdx.x + 256 * (blockIdx.x & 3);
     const double2 s1 = steer[bin];
     for (int ver = blockIdx.x >> 2; ver <= n_events; ver += gridDim.x >> 2)
@@ -478,7 +487,7 @@ __global__ __launch_bounds__(64) void mvdr_pairs_kernel(const short *__restrict_
     int ver = version_of(ver_base, snap_mask, j + sh.ver_block_off);
     if (sh.ver_row_off) ver -= *sh.ver_row_off;
     if (ver < 0) ver = 0;
-    const bool tabled = wtab && plan->n_events < kMvdrTableVersions;       // wave-uniform
+    const bool tabled = wtab && mvdr_tabled(plan->n_events, n_blocks);     // wave-uniform
 #endif
     const float4 *wrow = wtab + (size_t)ver * 1024;
     MvdrInv iv = {0.0, 0.0, 0.0, 0.0};
@@ -559,7 +568,7 @@ int launch_mvdr(hipStream_t s, const short *left, const short *right, long n_blo
     const long grid = (n_blocks + 7) / 8 * 8;
 #if JDSP_MVDR_PAIRS
     if (wtab)                                            // wtab: min(blocks + 1, kMvdrTableVersions) x 1024 float4, or NULL (no table)
-        hipLaunchKernelGGL(mvdr_weights_kernel, dim3(4096), dim3(256), 0, s, plan, rver, steer, wtab);     // 1,024 versions per pass
+        hipLaunchKernelGGL(mvdr_weights_kernel, dim3(4096), dim3(256), 0, s, plan, rver, steer, wtab, n_blocks);     // 1,024 versions per pass
     hipLaunchKernelGGL(mvdr_pairs_kernel, dim3((unsigned)grid), dim3(64), 0, s, left, right, n_blocks, calls_before, st_in,
                        st_out, ver_base, snap_mask, rver, steer, table, out, precast, sh, plan, (const float4 *)wtab);
 #else

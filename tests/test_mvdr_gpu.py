@@ -225,12 +225,12 @@ def test_mvdr_sharded_pause_heavy(eng, oracle, world):
     assert np.abs(got.astype(np.int32) - o_out.astype(np.int32)).max() <= 1
 
 
-@pytest.mark.parametrize("n_quiet", [1027, 8189, 8192, 8195])
-def test_weight_table_boundary(eng, oracle, n_quiet):
-    """Calls with fewer than 8,192 events read their per-bin weights from the per-version table (filled 1,024 versions per
-    pass), calls with more compute them per block: both sides of that boundary against the oracle (one quiet run of n
-    blocks = n - 1 or n events)."""
-    nb = n_quiet + 40
+@pytest.mark.parametrize("n_quiet,nb", [(1021, 1061), (1024, 1064), (1027, 1067), (1500, 5990), (1500, 6010),
+                                        (8189, 33000), (8195, 33000)])
+def test_weight_table_boundary(eng, oracle, n_quiet, nb):
+    """A call reads its per-bin weights from the per-version table (filled 1,024 versions per pass) when it has fewer than
+    1,024 events, or fewer than 8,192 and fewer than a quarter of its blocks; otherwise it computes them per block.  Both
+    sides of each of the three boundaries against the oracle (one quiet run of n blocks = n - 1 or n events)."""
     L, R = stereo(50 + n_quiet, nb, quiet=((20, n_quiet),))
     o_out, o_pre, o_corr, trace = oracle.mvdr_stream(L, R, 2.5e-4)
     m = eng.mvdr(2.5e-4)
