@@ -221,6 +221,16 @@ int jdsp_denoise_shard_finish_dev(jdsp_denoise *h, const float *last_all_dev, in
  * jdsp_denoise_vad_trace.  Any output pointer may be NULL. */
 int jdsp_vad_blocks(jdsp_ctx *ctx, const int16_t *pcm_host, long n_blocks, uint8_t *voice_host,
                     int64_t *energy_sum_host, int32_t *zcr_host);
+/* The same function at the other shapes it exists in.  variant JDSP_VAD_DENOISE: SS:121-156 = WF:261-296, frame
+ * [zeros(block_len), block], voice <=> energy > 700 or ZCR < 200.  JDSP_VAD_MVDR: BeamForming_MVDR_ver1.cpp:207-242,
+ * frame [zeros(block_len - 1), block, 0] (KEEP_LEN 511, :37), voice <=> energy > 700 (:233; the zero-crossing count
+ * is still computed and returned, as the reference prints it).  block_len 512 (the reference's BLOCK_LEN) or 256
+ * (FFT_PROCESSING_SIZE 512: BASELINE configs 3 and 5 as worded).  energy_sum = the integer sum of squares; the
+ * reference's dEnergy is energy_sum / (2 block_len). */
+#define JDSP_VAD_DENOISE 0
+#define JDSP_VAD_MVDR 1
+int jdsp_vad_blocks_ex(jdsp_ctx *ctx, int variant, int block_len, const int16_t *pcm_host, long n_blocks,
+                       uint8_t *voice_host, int64_t *energy_sum_host, int32_t *zcr_host);
 /* SpectralSubtraction / WienerFiltering (SS:201-264 / WF:162-235) with the CALLER's
  * pdEstimatedNoiseSpec (1024 doubles, host) instead of the handle's own VAD + estimate: only
  * the keep buffer, the overlap buffer and the call counter of the handle are used. */

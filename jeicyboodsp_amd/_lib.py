@@ -105,6 +105,7 @@ def _load():
         "jdsp_fastconv_process_dev": (i, [vp, vp, l, vp, vp, C.POINTER(l)]),
         "jdsp_fastconv_process": (i, [vp, vp, l, vp, vp, C.POINTER(l)]),
         "jdsp_vad_blocks": (i, [vp, vp, l, vp, vp, vp]),
+        "jdsp_vad_blocks_ex": (i, [vp, i, i, vp, l, vp, vp, vp]),
         "jdsp_denoise_apply": (i, [vp, vp, l, vp, vp, vp, C.POINTER(l)]),
         "jdsp_pitch_autocorr_dev": (i, [vp, vp, l, vp, vp, vp, vp]),
         "jdsp_pitch_autocorr": (i, [vp, vp, l, vp, vp, vp, vp]),

@@ -1,6 +1,7 @@
 // compat_mvdr_selftest.cpp -- BeamForming_MVDR_ver1.cpp's main() loop (:83-109) in structure, on the per-block
 // functions of jeicyboo_compat_mvdr.h.  usage: compat_mvdr_selftest left.raw right.raw out.bin [ooo]
 // out.bin: the int16 blocks the loop writes, then the final rgdSpatialCorr (4 doubles).
+// "vad" mode: VoiceActivityDetection (BF:207-242) on every block of left.raw, one byte per block.
 #include <cstdio>
 #include <cstring>
 
@@ -40,6 +41,17 @@ int main(int argc, char **argv)
         const int rc = out_of_order(l, r, w);
         fclose(l); fclose(r); fclose(w);
         return rc;
+    }
+    if (argc == 5 && !strcmp(argv[4], "vad")) {
+        FILE *l = fopen(argv[1], "rb"), *w = fopen(argv[3], "wb");
+        if (!l || !w) return 1;
+        short blk[BLOCK_LEN];
+        while (fread(blk, sizeof(short), BLOCK_LEN, l) == BLOCK_LEN) {
+            const unsigned char v = VoiceActivityDetection(blk, BLOCK_LEN) ? 1 : 0;
+            fwrite(&v, 1, 1, w);
+        }
+        fclose(l); fclose(w);
+        return 0;
     }
     if (argc != 4) return 1;
     FILE *fpRead1 = fopen(argv[1], "rb"), *fpRead2 = fopen(argv[2], "rb"), *fpWrite = fopen(argv[3], "wb");

@@ -1,6 +1,6 @@
 // compat_selftest.cpp -- drives the reference-signature functions exactly the way the
 // reference main()s do (one block per call) and dumps what they return, for tests/ to compare
-// with the CPU checker.  usage: compat_selftest <ss|wf|conv|mfcc|mfccsteps|pitch|awgn|fft|dft|gmm|prob|hmm> in.raw out.bin [taps.f64 | params.bin]
+// with the CPU checker.  usage: compat_selftest <ss|wf|vad|conv|mfcc|mfccsteps|pitch|awgn|fft|dft|gmm|prob|hmm> in.raw out.bin [taps.f64 | params.bin]
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -39,6 +39,12 @@ int main(int argc, char **argv)
             } else iter = 0;
             bool ok = !strcmp(what, "ss") ? SpectralSubtraction(in, noise, ob, 512) : WienerFiltering(in, noise, ob, 512);
             if (ok) fwrite(ob, 2, 512, out);
+        }
+    } else if (!strcmp(what, "vad")) {
+        // VoiceActivityDetection (SS:121-156) alone, one byte per block
+        for (size_t b = 0; b + 512 <= pcm.size(); b += 512) {
+            const unsigned char v = VoiceActivityDetection(&pcm[b], 512) ? 1 : 0;
+            fwrite(&v, 1, 1, out);
         }
     } else if (!strcmp(what, "conv")) {
         static double filt[8192][2];

@@ -37,7 +37,7 @@ bool VoiceActivityDetection(short *block, int n)
 {
     if (n != 512) { fprintf(stderr, "VoiceActivityDetection: iFrameCount must be 512\n"); abort(); }
     int64_t e = 0;
-    CK(jdsp_vad_blocks(context(), block, 1, nullptr, &e, nullptr));
+    CK(jdsp_vad_blocks_ex(context(), JDSP_VAD_MVDR, 512, block, 1, nullptr, &e, nullptr));   // frame offset KEEP_LEN 511 (:37)
     return e > 716800;                                    // dEnergy = sum / 1024 > THRESHOLD_OF_ENERGY 700 (:233)
 }
 

@@ -311,28 +311,36 @@ int jdsp_denoise_apply(jdsp_denoise *h, const int16_t *pcm_host, long n_blocks, 
     return rc;
 }
 
-int jdsp_vad_blocks(jdsp_ctx *ctx, const int16_t *pcm_host, long n_blocks, uint8_t *voice_host,
-                    int64_t *energy_sum_host, int32_t *zcr_host)
+int jdsp_vad_blocks_ex(jdsp_ctx *ctx, int variant, int block_len, const int16_t *pcm_host, long n_blocks,
+                       uint8_t *voice_host, int64_t *energy_sum_host, int32_t *zcr_host)
 {
     if (!ctx) return JDSP_EINVAL;
+    if ((variant != JDSP_VAD_DENOISE && variant != JDSP_VAD_MVDR) || (block_len != 512 && block_len != 256))
+        return fail(ctx, JDSP_EINVAL, "jdsp_vad_blocks_ex: variant 0 | 1, block_len 512 | 256");
     if (n_blocks < 0 || (n_blocks > 0 && !pcm_host)) return fail(ctx, JDSP_EINVAL, "jdsp_vad_blocks: bad argument");
     if (n_blocks == 0) return JDSP_OK;
     JDSP_HIP(ctx, hipSetDevice(ctx->device));
-    int rc = jdsp::ensure_vad_window(ctx);
+    const double *w = nullptr;
+    int rc = jdsp::ensure_vad_window_ex(ctx, variant, block_len, &w);
     if (rc) return rc;
-    const size_t n = (size_t)n_blocks;
+    const size_t n = (size_t)n_blocks, in_bytes = n * (size_t)block_len * sizeof(int16_t);
     int16_t *d_in = nullptr;
     unsigned char *d_v = nullptr;
     long long *d_e = nullptr;
     int *d_z = nullptr;
-    hipError_t e = hipMalloc((void **)&d_in, n * 1024);
+    hipError_t e = hipMalloc((void **)&d_in, in_bytes);
     if (e == hipSuccess) e = hipMalloc((void **)&d_v, n);
     if (e == hipSuccess) e = hipMalloc((void **)&d_e, n * 8);
     if (e == hipSuccess) e = hipMalloc((void **)&d_z, n * 4);
     hipStream_t s = ctx->stream;
-    if (e == hipSuccess) e = hipMemcpyAsync(d_in, pcm_host, n * 1024, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_in, pcm_host, in_bytes, hipMemcpyHostToDevice, s);
     if (e != hipSuccess) rc = fail(ctx, JDSP_EHIP, "jdsp_vad_blocks: staging", e);
-    if (!rc && jdsp::launch_vad(s, d_in, n_blocks, ctx->vad_w_hi, 1, d_v, d_e, d_z)) rc = fail(ctx, JDSP_EHIP, "vad launch", hipGetLastError());
+    const int use_zcr = variant == JDSP_VAD_DENOISE;                    // BF:233 tests the energy alone
+    if (!rc && (block_len == 512 ? jdsp::launch_vad(s, d_in, n_blocks, w, use_zcr, d_v, d_e, d_z)
+                                 : jdsp::launch_vad256(s, d_in, n_blocks, w, d_v, d_e, d_z, use_zcr))) {
+        const hipError_t le = hipGetLastError();
+        rc = fail(ctx, JDSP_EHIP, "vad launch", le);
+    }
     if (!rc && voice_host && (e = hipMemcpyAsync(voice_host, d_v, n, hipMemcpyDeviceToHost, s)) != hipSuccess) rc = fail(ctx, JDSP_EHIP, "jdsp_vad_blocks: D2H", e);
     if (!rc && energy_sum_host && (e = hipMemcpyAsync(energy_sum_host, d_e, n * 8, hipMemcpyDeviceToHost, s)) != hipSuccess) rc = fail(ctx, JDSP_EHIP, "jdsp_vad_blocks: D2H", e);
     if (!rc && zcr_host && (e = hipMemcpyAsync(zcr_host, d_z, n * 4, hipMemcpyDeviceToHost, s)) != hipSuccess) rc = fail(ctx, JDSP_EHIP, "jdsp_vad_blocks: D2H", e);
@@ -342,6 +350,12 @@ int jdsp_vad_blocks(jdsp_ctx *ctx, const int16_t *pcm_host, long n_blocks, uint8
     if (d_e) (void)hipFree(d_e);
     if (d_z) (void)hipFree(d_z);
     return rc;
+}
+
+int jdsp_vad_blocks(jdsp_ctx *ctx, const int16_t *pcm_host, long n_blocks, uint8_t *voice_host,
+                    int64_t *energy_sum_host, int32_t *zcr_host)
+{
+    return jdsp_vad_blocks_ex(ctx, JDSP_VAD_DENOISE, 512, pcm_host, n_blocks, voice_host, energy_sum_host, zcr_host);
 }
 
 /* ---- multi-GPU: one rank's share of a stream (include/jdsp.h "sharded denoise") ------------- */

@@ -49,6 +49,20 @@ int ensure_vad_window(jdsp_ctx *ctx)
     return 0;
 }
 
+int ensure_vad_window_ex(jdsp_ctx *ctx, int variant, int block_len, const double **w_out)
+{
+    const int bi = block_len == 512 ? 0 : 1;
+    if (!ctx->vad_w_ex[variant][bi]) {
+        const int n = 2 * block_len, keep = variant == 0 ? block_len : block_len - 1;
+        double w[512];
+        for (int i = 0; i < block_len; i++) w[i] = (0.54 - 0.46 * cos(2 * 3.141592 * (keep + i) / (n - 1)));   // SS:131 / BF:217
+        JDSP_HIP(ctx, hipMalloc((void **)&ctx->vad_w_ex[variant][bi], sizeof(double) * block_len));
+        JDSP_HIP(ctx, hipMemcpy(ctx->vad_w_ex[variant][bi], w, sizeof(double) * block_len, hipMemcpyHostToDevice));
+    }
+    *w_out = ctx->vad_w_ex[variant][bi];
+    return 0;
+}
+
 }  // namespace jdsp
 
 using jdsp::fail;
@@ -103,6 +117,9 @@ int jdsp_destroy(jdsp_ctx *ctx)
     for (auto &p : ctx->c2c_tw)
         if (p) (void)hipFree(p);
     if (ctx->vad_w_hi) (void)hipFree(ctx->vad_w_hi);
+    for (auto &row : ctx->vad_w_ex)
+        for (auto &p : row)
+            if (p) (void)hipFree(p);
     if (ctx->win512) (void)hipFree(ctx->win512);
     if (ctx->win512_hann) (void)hipFree(ctx->win512_hann);
     if (ctx->stft1024_table_hann) (void)hipFree(ctx->stft1024_table_hann);

@@ -35,6 +35,7 @@ struct jdsp_ctx {
     double *stft_f64_table = nullptr;  // FP64 STFT: window + split twiddles (fft_c2c_kernels.hip)
     float2 *conv_tw4096 = nullptr, *conv_tw8192 = nullptr;
     double *vad_w_hi = nullptr;        // second half of the FP64 Hamming window
+    double *vad_w_ex[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // jdsp_vad_blocks_ex: [variant][block 512 | 256]
     // pinned-host pipeline of jdsp_stft_i16: copy-in / compute / copy-out on three streams
     hipStream_t pipe_in = nullptr, pipe_out = nullptr;
     hipEvent_t pipe_ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -174,6 +175,9 @@ int launch_shard_rows(hipStream_t s, const float *summaries_all, int rank, long 
 int launch_shard_row0(hipStream_t s, const float *last_all, int rank, float *rows);
 int ensure_stft1024_table(jdsp_ctx *ctx);
 int ensure_vad_window(jdsp_ctx *ctx);
+// FP64 Hamming(2 block_len) over the positions a block occupies in the VAD's frame: keep + i, keep = block_len (SS:127-128)
+// or block_len - 1 (BeamForming_MVDR_ver1.cpp:37,213-214); cached per context
+int ensure_vad_window_ex(jdsp_ctx *ctx, int variant, int block_len, const double **w);
 // fastconv_kernels.hip
 // (fastconv) Sample `pos` of this call's stream (pos < 0: history carried in the handle).  Samples of
 // the first n_hist blocks of a stream never reach the transform in the reference (its queue

@@ -80,6 +80,18 @@ class Engine:
     def synchronize(self):
         self._ck(L.jdsp_synchronize(self._h))
 
+    # ---- VoiceActivityDetection on its own (SS:121-156 = WF:261-296; BF:207-242) ----
+    def vad_blocks(self, blocks, variant="denoise"):
+        """blocks int16 [n, 512 | 256] (host) -> (voice uint8 [n], energy sums int64 [n], zero crossings int32 [n]).
+        variant "denoise": energy > 700 or ZCR < 200; "mvdr": BeamForming_MVDR_ver1.cpp's frame offset, energy only."""
+        blocks = np.ascontiguousarray(np.atleast_2d(blocks), np.int16)
+        n, bl = blocks.shape
+        v = np.zeros(n, np.uint8)
+        e = np.zeros(n, np.int64)
+        z = np.zeros(n, np.int32)
+        self._ck(L.jdsp_vad_blocks_ex(self._h, {"denoise": 0, "mvdr": 1}[variant], bl, _vp(blocks), n, _vp(v), _vp(e), _vp(z)))
+        return v, e, z
+
     # ---- FFTAlgorithm_ver2.cpp ------------------------------------------------
     def bitrev_table(self, n_fft, block_len=None):
         """Bitrev table (FFTAlgorithm_ver2.cpp:186-202) computed on the device; int16[n_fft]."""

@@ -566,20 +566,6 @@ void orc_pitch_stream(const short *pcm, long n_blocks, int *arg, double *rmax, d
 #define MV_BLOCK 512
 #define MV_KEEP 511
 
-/* :207-242: frame = [zeros(511) (keep buffer never updated, :240 unreachable), block, 0];
- * only the energy decides (:233); the zero-crossing count is computed and ignored. */
-static int mvdr_vad(const short *block)
-{
-    double e = 0.0;
-    for (int i = 0; i < MV_BLOCK; i++) {
-        int p = MV_KEEP + i;
-        short s = (short)(block[i] * (0.54 - 0.46 * cos(2 * PI_APPS * p / (MV_N - 1))));   /* :217 */
-        e += pow(s, 2.0);                                                                   /* :221 */
-    }
-    e /= MV_N;                                                                              /* :229 */
-    return e > 700.0;                                                                       /* :233 */
-}
-
 /* EstimateSpatialCorrMtx :244-270: one [previous block, block] frame per channel, ADDED to R (row-major) */
 void orc_mvdr_estimate(const short *temp_l, const short *temp_r, double *R4)
 {
@@ -595,6 +581,29 @@ void orc_mvdr_estimate(const short *temp_l, const short *temp_r, double *R4)
         R4[3] += (pow(FR[i].re, 2.0) + pow(FR[i].im, 2.0)) / MV_N;
     }
     free(fl); free(FL); free(fr); free(FR);
+}
+
+/* BF:207-242 in full, as its printf shows it (:232): frame = [zeros(KEEP_LEN = n/2 - 1), block(n/2), 0]; every sample
+ * is windowed and truncated back to short (:217), the energy summed (:221), the zero crossings counted against the
+ * NOT-yet-windowed next sample (:225; the last pair reads one short past the array: defined as 0 here, and the sample
+ * in front of it, frame[n-1], is 0 anyway); only the energy decides (:233). */
+int orc_mvdr_vad_block(const short *block, int n_fft, double *energy, int *zcr)
+{
+    const int n = n_fft, B = n / 2, K = n / 2 - 1;
+    short *s = (short *)calloc((size_t)n + 1, sizeof(short));
+    double e = 0.0;
+    int z = 0;
+    memcpy(s + K, block, sizeof(short) * (size_t)B);
+    for (int i = 0; i < n; i++) {
+        s[i] = (short)(s[i] * (0.54 - 0.46 * cos(2 * PI_APPS * i / (n - 1))));
+        e += pow(s[i], 2.0);
+        if (s[i] * s[i + 1] < 0) z++;
+    }
+    e /= n;
+    if (energy) *energy = e;
+    if (zcr) *zcr = z;
+    free(s);
+    return e > 700.0;
 }
 
 /* ProcessMVDR's statics (:130-131,:137) */
@@ -664,7 +673,7 @@ long orc_mvdr_stream(const short *left, const short *right, long n_blocks, doubl
     long n_out = 0;
     for (long b = 0; b < n_blocks; b++) {
         const short *L = left + (size_t)b * MV_BLOCK, *Rr = right + (size_t)b * MV_BLOCK;
-        if (!mvdr_vad(L)) {                                            /* :191-211 */
+        if (!orc_mvdr_vad_block(L, MV_N, NULL, NULL)) {                                            /* :191-211 */
             iter++;
             if (iter > 1) {
                 memcpy(temp_l + MV_BLOCK, L, sizeof(short) * MV_BLOCK);
@@ -714,20 +723,6 @@ static int solve_cplx(int n, double complex A[MVN_MAX][MVN_MAX], double complex 
     return 0;
 }
 
-/* the energy VAD of BeamForming_MVDR_ver1.cpp:207-242 on a frame of n samples [zeros(n/2 - 1), block(n/2), 0] */
-static int mvdr_vad_n(const short *block, int n)
-{
-    const int B = n / 2, K = n / 2 - 1;
-    double e = 0.0;
-    for (int i = 0; i < B; i++) {
-        int p = K + i;
-        short s = (short)(block[i] * (0.54 - 0.46 * cos(2 * PI_APPS * p / (n - 1))));      /* :217 */
-        e += pow(s, 2.0);                                                                   /* :221 */
-    }
-    e /= n;                                                                                 /* :229 */
-    return e > 700.0;                                                                       /* :233 */
-}
-
 long orc_mvdrn_stream2(const short *pcm, long chan_stride, int n_mics, long n_blocks, const double *delays,
                        double loading, int n_fft, short *out, double *pre_cast)
 {
@@ -742,7 +737,7 @@ long orc_mvdrn_stream2(const short *pcm, long chan_stride, int n_mics, long n_bl
     long n_out = 0;
     for (long b = 0; b < n_blocks; b++) {
         const short *c0 = pcm + (size_t)b * B;
-        if (!mvdr_vad_n(c0, N)) {
+        if (!orc_mvdr_vad_block(c0, N, NULL, NULL)) {
             iter++;
             if (iter > 1) {                       /* frame = [block b-1, block b] of every microphone */
                 for (int m = 0; m < M; m++) {

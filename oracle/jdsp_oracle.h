@@ -61,6 +61,8 @@ void orc_stft(const short *pcm, long n_frames, int n, int hop, orc_cplx *spec);
  * frame[n] at i == n-1 (:139) is defined here as 0.  Returns 1 = voice.
  * energy/zcr may be NULL. */
 int orc_vad_block(const short *block, int block_len, double *energy, int *zcr);
+/* BeamForming_MVDR_ver1.cpp:207-242: the same function over [zeros(n_fft/2 - 1), block(n_fft/2), 0], energy decides */
+int orc_mvdr_vad_block(const short *block, int n_fft, double *energy, int *zcr);
 
 /* SS:62-119,159-264 / WF:52-235: the whole per-block state machine. */
 typedef struct orc_denoise orc_denoise;

@@ -55,6 +55,8 @@ class Oracle:
         L.orc_stft.argtypes = [_c_short_p, C.c_long, C.c_int, C.c_int, _c_double_p]
         L.orc_vad_block.argtypes = [_c_short_p, C.c_int, _c_double_p, _c_int_p]
         L.orc_vad_block.restype = C.c_int
+        L.orc_mvdr_vad_block.argtypes = [_c_short_p, C.c_int, _c_double_p, _c_int_p]
+        L.orc_mvdr_vad_block.restype = C.c_int
         L.orc_denoise_stream.argtypes = [C.c_int, _c_short_p, C.c_long, _c_short_p, _c_double_p]
         L.orc_denoise_stream.restype = C.c_long
         L.orc_denoise_stream2.argtypes = [C.c_int, C.c_int, _c_short_p, C.c_long, _c_short_p, _c_double_p]
@@ -200,6 +202,14 @@ class Oracle:
         e = C.c_double()
         z = C.c_int()
         v = self.lib.orc_vad_block(_p(block, _c_short_p), block.size, C.byref(e), C.byref(z))
+        return bool(v), e.value, z.value
+
+    def mvdr_vad_block(self, block):
+        """BF:207-242 on one block of n_fft/2 samples: (voice, energy, zcr)."""
+        block = np.ascontiguousarray(block, np.int16)
+        e = C.c_double()
+        z = C.c_int()
+        v = self.lib.orc_mvdr_vad_block(_p(block, _c_short_p), 2 * block.size, C.byref(e), C.byref(z))
         return bool(v), e.value, z.value
 
     def denoise_stream(self, mode, pcm, block=512):
@@ -416,6 +426,118 @@ class RefFftAlg:
         out = np.zeros_like(x)
         self.lib.ref_IFFTProcess(_p(x, _c_double_p), _p(out, _c_double_p), x.size)
         return out
+
+
+class capture_c_stdout:
+    """Sends the C library's stdout (fd 1) to a temporary file for the duration; .text afterwards."""
+
+    def __enter__(self):
+        import sys
+        import tempfile
+        sys.stdout.flush()
+        C.CDLL(None).fflush(None)
+        self.tmp = tempfile.TemporaryFile()
+        self.saved = os.dup(1)
+        os.dup2(self.tmp.fileno(), 1)
+        return self
+
+    def __exit__(self, *a):
+        C.CDLL(None).fflush(None)
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        self.tmp.seek(0)
+        self.text = self.tmp.read().decode()
+        self.tmp.close()
+
+
+class RefMfccTail:
+    """MelFilterBankInit / MelFilterBank / DCT / Liftering and the three global tables of
+    MFCCFeatureExtraction_auto_version1.cpp (:13-42, :116-192), compiled from the reference checkout."""
+
+    def __init__(self, path):
+        L = self.lib = C.CDLL(path)
+        L.ref_mfcc_consts.argtypes = [_c_int_p]
+        L.ref_mfcc_half_rate.restype = C.c_double
+        L.ref_mfcc_tables.argtypes = [_c_double_p, _c_int_p, _c_double_p]
+        L.ref_MelFilterBank.argtypes = [_c_double_p, _c_double_p]
+        L.ref_DCT.argtypes = [_c_double_p, _c_double_p]
+        L.ref_Liftering.argtypes = [_c_double_p]
+        c = np.zeros(5, np.int32)
+        L.ref_mfcc_consts(_p(c, _c_int_p))
+        self.n_cep, self.n_bins, self.n_chan, self.lifter, self.block_len = (int(v) for v in c)
+        self.half_rate = L.ref_mfcc_half_rate()
+        L.ref_MelFilterBankInit()
+
+    def tables(self):
+        mel = np.zeros(self.n_chan + 1, np.float64)
+        fi = np.zeros(self.n_bins, np.int32)
+        fb = np.zeros(self.n_bins, np.float64)
+        self.lib.ref_mfcc_tables(_p(mel, _c_double_p), _p(fi, _c_int_p), _p(fb, _c_double_p))
+        return mel, fi, fb
+
+    def mel_filterbank(self, mag):
+        mag = np.ascontiguousarray(np.atleast_2d(mag), np.float64)
+        assert mag.shape[1] == self.n_bins
+        out = np.zeros((mag.shape[0], self.n_chan), np.float64)
+        for r in range(mag.shape[0]):
+            self.lib.ref_MelFilterBank(_p(mag[r], _c_double_p), _p(out[r], _c_double_p))
+        return out
+
+    def dct(self, mel, accumulate_into=None):
+        mel = np.ascontiguousarray(np.atleast_2d(mel), np.float64)
+        out = np.zeros((mel.shape[0], self.n_cep), np.float64) if accumulate_into is None else \
+            np.ascontiguousarray(np.atleast_2d(accumulate_into), np.float64).copy()
+        for r in range(mel.shape[0]):
+            self.lib.ref_DCT(_p(mel[r], _c_double_p), _p(out[r], _c_double_p))
+        return out
+
+    def liftering(self, cep):
+        cep = np.ascontiguousarray(np.atleast_2d(cep), np.float64).copy()
+        for r in range(cep.shape[0]):
+            self.lib.ref_Liftering(_p(cep[r], _c_double_p))
+        return cep
+
+
+class RefVad:
+    """VoiceActivityDetection of SpectralSubtraction_final.cpp ('ss'), WienerFilter_final.cpp ('wf') or
+    BeamForming_MVDR_ver1.cpp ('bf'), compiled from the reference checkout."""
+
+    def __init__(self, path):
+        L = self.lib = C.CDLL(path)
+        L.ref_vad_paint.argtypes = [C.c_short]
+        L.ref_VoiceActivityDetection.argtypes = [_c_short_p, C.c_int, C.c_short]
+        L.ref_VoiceActivityDetection.restype = C.c_int
+        L.ref_vad_consts.argtypes = [_c_double_p]
+        c = np.zeros(6, np.float64)
+        L.ref_vad_consts(_p(c, _c_double_p))
+        self.thr_energy, self.thr_zcr, self.keep_len, self.block_len, self.n_fft, self.pi = c
+
+    def run(self, blocks, fill=0):
+        """blocks int16 [n, block_len] -> (flags int32 [n], printed energy float64 [n], printed ZCR int32 [n]).
+        `fill`: the value painted over the callee's stack depth before every call = what SS:139's over-read finds."""
+        blocks = np.ascontiguousarray(np.atleast_2d(blocks), np.int16)
+        flags = np.zeros(blocks.shape[0], np.int32)
+        with capture_c_stdout() as cap:
+            for i, b in enumerate(blocks):
+                flags[i] = self.lib.ref_VoiceActivityDetection(_p(b, _c_short_p), b.size, fill)
+        import re
+        rows = re.findall(r"dEnergy\s+(\S+)\s*,\s*dZCR\s+(-?\d+)", cap.text)
+        assert len(rows) == blocks.shape[0], (len(rows), blocks.shape)
+        return flags, np.array([float(r[0]) for r in rows]), np.array([int(r[1]) for r in rows], np.int32)
+
+
+def ref_slice_path(name):
+    return os.path.join(ORACLE_DIR, "_ref", "libref_%s.so" % name)
+
+
+def load_ref_mfcc_tail():
+    p = ref_slice_path("mfcc_tail")
+    return RefMfccTail(p) if os.path.exists(p) else None
+
+
+def load_ref_vad(which):
+    p = ref_slice_path("vad_" + which)
+    return RefVad(p) if os.path.exists(p) else None
 
 
 def ref_path(block_len=512):

@@ -408,3 +408,17 @@ def test_compat_mfcc_sub_steps_and_probability(tmp_path, oracle):
                       for k in range(4)] for v in vec])
     ok = want > 0
     assert np.abs(p[ok] / want[ok] - 1).max() < 1e-10 and np.array_equal(p == 0, want == 0)
+
+
+def test_compat_vad_functions_equal_the_compiled_reference(tmp_path, golden_dir):
+    """VoiceActivityDetection of libjeicyboo_compat.so (SS:121-156 = WF:261-296) and of libjeicyboo_compat_mvdr.so
+    (BF:207-242: frame offset 511, energy only), one block per call, against tests/golden/vad.npz = what the
+    reference's own functions returned for the same blocks."""
+    subprocess.check_call(["make", "-s", "-C", COMPAT])
+    g = np.load(os.path.join(golden_dir, "vad.npz"), allow_pickle=False)
+    g["blocks"].tofile(tmp_path / "blocks.raw")
+    run("compat_selftest", "vad", tmp_path / "blocks.raw", tmp_path / "ss.bin")
+    assert np.array_equal(np.fromfile(tmp_path / "ss.bin", np.uint8), g["ss_flags"])
+    assert np.array_equal(g["ss_flags"], g["wf_flags"])
+    run("compat_mvdr_selftest", tmp_path / "blocks.raw", tmp_path / "blocks.raw", tmp_path / "bf.bin", "vad")
+    assert np.array_equal(np.fromfile(tmp_path / "bf.bin", np.uint8), g["bf_flags"])
