@@ -38,7 +38,10 @@
 extern "C" {
 #endif
 
-#define JDSP_ABI_VERSION 1
+/* 2: jdsp_vad_blocks_ex added; jdsp_denoise_apply and jdsp_denoise_shard_* accept 512-point streams;
+ *    jdsp_denoise_vad_trace's energies / counts follow the option's value at the time of the traced call;
+ *    jdsp_set_option("stft.read_pass") accepts -1 / 0 / 1 only.  (1: rounds 1-2.) */
+#define JDSP_ABI_VERSION 2
 
 enum {
     JDSP_OK = 0,
@@ -169,7 +172,7 @@ int jdsp_denoise_create(jdsp_ctx *ctx, int mode, jdsp_denoise **out);
  * KEEP_LEN = hop (SS:53-55 / WF:42-44 are 1024 / 512 / 512 = jdsp_denoise_create; BASELINE config 3 words the workload
  * "512-pt STFT 50 % hop" = (512, 256)).  Blocks are then hop samples long everywhere below, the noise estimate has
  * n_fft entries, and the thresholds stay the reference's (energy 700, ZCR 200, latch at run length 10).  Supported:
- * (1024, 512) and (512, 256); jdsp_denoise_apply and the sharded entries take 1024-point streams only. */
+ * (1024, 512) and (512, 256), on every entry below (batched, per-block jdsp_denoise_apply, sharded). */
 int jdsp_denoise_create_cfg(jdsp_ctx *ctx, int mode, int n_fft, int hop, jdsp_denoise **out);
 int jdsp_denoise_block_len(const jdsp_denoise *h);
 int jdsp_denoise_destroy(jdsp_denoise *h);
@@ -186,18 +189,21 @@ int jdsp_denoise_process_dev(jdsp_denoise *h, const int16_t *pcm_dev, long n_blo
                              float *precast_dev, long *n_out_blocks);
 int jdsp_denoise_process(jdsp_denoise *h, const int16_t *pcm_host, long n_blocks, int16_t *out_host,
                          float *precast_host, long *n_out_blocks);
-/* Current rgdEstimatedNS (1024 doubles, host).  Synchronises. */
+/* Current rgdEstimatedNS (n_fft doubles, host).  Synchronises. */
 int jdsp_denoise_noise(jdsp_denoise *h, double *noise_host);
 /* VoiceActivityDetection results of the first n blocks of the last process call:
  * voice flag, sum of squared truncated samples (dEnergy*1024, SS:135) and dZCR (SS:140).
  * Any pointer may be NULL.  The flags are always there; energies and counts only when the "vad_trace" option was
- * set before the call (JDSP_EINVAL otherwise).  Synchronises. */
+ * set WHEN THAT CALL RAN (JDSP_EINVAL otherwise -- since ABI version 2; setting it afterwards does not make a
+ * trace appear).  Synchronises. */
 int jdsp_denoise_vad_trace(jdsp_denoise *h, long n, uint8_t *voice_host, int64_t *energy_sum_host,
                            int32_t *zcr_host);
 
 /* Sharded denoise: one rank's share of ONE global stream of n_total blocks (multi-GPU,
  * SURVEY §8e).  The rank owns global blocks [b0, b1); pcm_ext_dev holds global blocks
- * [ext0, b1) with ext0 = max(b0 - 2, 0) (two halo blocks rebuild the overlap tail).  Between
+ * [ext0, b1) with ext0 = max(b0 - 2, 0) (two halo blocks rebuild the overlap tail); blocks are
+ * jdsp_denoise_block_len() samples (512, or 256 on 512-point frames: the exchanged buffers keep
+ * their 1025-float size, entries past n_fft are unused).  Between
  * the steps the caller all-gathers three small buffers across ranks (any transport; RCCL in
  * jeicyboodsp_amd/sharding.py):
  *   1. shard_vad      -> flags_own (b1-b0 bytes)          all-gather -> flags_all (n_total bytes)
@@ -232,7 +238,7 @@ int jdsp_vad_blocks(jdsp_ctx *ctx, const int16_t *pcm_host, long n_blocks, uint8
 int jdsp_vad_blocks_ex(jdsp_ctx *ctx, int variant, int block_len, const int16_t *pcm_host, long n_blocks,
                        uint8_t *voice_host, int64_t *energy_sum_host, int32_t *zcr_host);
 /* SpectralSubtraction / WienerFiltering (SS:201-264 / WF:162-235) with the CALLER's
- * pdEstimatedNoiseSpec (1024 doubles, host) instead of the handle's own VAD + estimate: only
+ * pdEstimatedNoiseSpec (n_fft doubles, host) instead of the handle's own VAD + estimate: only
  * the keep buffer, the overlap buffer and the call counter of the handle are used. */
 int jdsp_denoise_apply(jdsp_denoise *h, const int16_t *pcm_host, long n_blocks, const double *noise_host,
                        int16_t *out_host, float *precast_host, long *n_out_blocks);

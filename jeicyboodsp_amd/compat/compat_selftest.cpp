@@ -26,24 +26,26 @@ int main(int argc, char **argv)
     std::vector<short> pcm = slurp(argv[2]);
     FILE *out = fopen(argv[3], "wb");
     if (!strcmp(what, "ss") || !strcmp(what, "wf")) {
-        // SpectralSubtraction_final.cpp:92-113 verbatim in structure
+        // SpectralSubtraction_final.cpp:92-113 verbatim in structure; argv[4] = BLOCK_LEN (default 512, or 256)
+        const int B = argc > 4 ? atoi(argv[4]) : 512;
         short temp[512] = {0}, ob[512] = {0};
         double noise[1024] = {0};
         int iter = 0;
-        for (size_t b = 0; b + 512 <= pcm.size(); b += 512) {
+        for (size_t b = 0; b + B <= pcm.size(); b += B) {
             short *in = &pcm[b];
-            if (!VoiceActivityDetection(in, 512)) {
+            if (!VoiceActivityDetection(in, B)) {
                 iter++;
-                if (iter == 1) memcpy(temp, in, sizeof(temp));
-                else if (iter > 1) EstimateNoiseSpectrum(temp, iter, in, noise, 512);
+                if (iter == 1) memcpy(temp, in, sizeof(short) * B);
+                else if (iter > 1) EstimateNoiseSpectrum(temp, iter, in, noise, B);
             } else iter = 0;
-            bool ok = !strcmp(what, "ss") ? SpectralSubtraction(in, noise, ob, 512) : WienerFiltering(in, noise, ob, 512);
-            if (ok) fwrite(ob, 2, 512, out);
+            bool ok = !strcmp(what, "ss") ? SpectralSubtraction(in, noise, ob, B) : WienerFiltering(in, noise, ob, B);
+            if (ok) fwrite(ob, 2, B, out);
         }
     } else if (!strcmp(what, "vad")) {
-        // VoiceActivityDetection (SS:121-156) alone, one byte per block
-        for (size_t b = 0; b + 512 <= pcm.size(); b += 512) {
-            const unsigned char v = VoiceActivityDetection(&pcm[b], 512) ? 1 : 0;
+        // VoiceActivityDetection (SS:121-156) alone, one byte per block; argv[4] = BLOCK_LEN (default 512)
+        const int B = argc > 4 ? atoi(argv[4]) : 512;
+        for (size_t b = 0; b + B <= pcm.size(); b += B) {
+            const unsigned char v = VoiceActivityDetection(&pcm[b], B) ? 1 : 0;
             fwrite(&v, 1, 1, out);
         }
     } else if (!strcmp(what, "conv")) {

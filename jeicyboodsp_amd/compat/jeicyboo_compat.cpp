@@ -10,6 +10,7 @@
 namespace {
 
 int g_block_len = 512;
+int g_frame_count = 0;        // iFrameCount of the denoise stream in progress (0: none yet)
 int g_device = -1;
 jdsp_ctx *g_ctx = nullptr;
 jdsp_denoise *g_dn[2] = {nullptr, nullptr};
@@ -66,6 +67,7 @@ void JeicybooResetStreams(void)
     g_conv = nullptr;
     if (g_mfcc) jdsp_mfcc_destroy(g_mfcc);
     g_mfcc = nullptr;
+    g_frame_count = 0;
     memset(g_avg, 0, sizeof(g_avg));
     memset(g_est_keep, 0, sizeof(g_est_keep));
     memset(g_mfcc_keep, 0, sizeof(g_mfcc_keep));
@@ -102,41 +104,53 @@ void IFFTProcess(COMPLEX *in, COMPLEX *out, int n)
 }
 
 // ---- SpectralSubtraction_final.cpp / WienerFilter_final.cpp --------------------------------
+// iFrameCount is BLOCK_LEN = KEEP_LEN (SS:53-54) and FFT_PROCESSING_SIZE is twice that (SS:55): 512 / 1024 as the
+// reference defines them, or 256 / 512 (BASELINE config 3: "512-pt STFT 50 % hop").  A stream keeps the size of its
+// first call; JeicybooResetStreams() forgets it.
+static int frame_count(const char *who, int n)
+{
+    if (n != 512 && n != 256) { fprintf(stderr, "%s: iFrameCount must be 512 or 256\n", who); abort(); }
+    if (g_frame_count && n != g_frame_count) { fprintf(stderr, "%s: iFrameCount changed inside a stream\n", who); abort(); }
+    g_frame_count = n;
+    return n;
+}
+
 bool VoiceActivityDetection(short *block, int n)
 {
-    if (n != 512) { fprintf(stderr, "VoiceActivityDetection: iFrameCount must be 512\n"); abort(); }
+    frame_count("VoiceActivityDetection", n);
     uint8_t v = 0;
-    CK(jdsp_vad_blocks(JeicybooContext(), block, 1, &v, nullptr, nullptr));
+    CK(jdsp_vad_blocks_ex(JeicybooContext(), JDSP_VAD_DENOISE, n, block, 1, &v, nullptr, nullptr));
     return v != 0;
 }
 
 void EstimateNoiseSpectrum(short *temp, int iter, short *in, double *noise, int n)
 {
-    if (n != 512) { fprintf(stderr, "EstimateNoiseSpectrum: iFrameCount must be 512\n"); abort(); }
-    if (iter == 2) memcpy(g_est_keep, temp, sizeof(g_est_keep));                         // SS:165-167
+    frame_count("EstimateNoiseSpectrum", n);
+    const int N = 2 * n;
+    if (iter == 2) memcpy(g_est_keep, temp, sizeof(short) * n);                           // SS:165-167
     short frame[1024];
-    memcpy(frame, g_est_keep, sizeof(g_est_keep));
-    memcpy(frame + 512, in, sizeof(short) * 512);
+    memcpy(frame, g_est_keep, sizeof(short) * n);
+    memcpy(frame + n, in, sizeof(short) * n);
     static jdsp_c32 spec[1024];
     long nf = 0;
-    CK(jdsp_stft_i16(JeicybooContext(), frame, 1024, 1024, 512, spec, &nf));             // SS:168-180 on the GPU
-    for (int i = 0; i < 1024; i++) {                                                      // SS:182-187
+    CK(jdsp_stft_i16(JeicybooContext(), frame, N, N, n, spec, &nf));                      // SS:168-180 on the GPU
+    for (int i = 0; i < N; i++) {                                                         // SS:182-187
         g_avg[i] += sqrt((double)spec[i].re * spec[i].re + (double)spec[i].im * spec[i].im);
         if (iter >= 3) g_avg[i] /= 2.0;
     }
-    if (iter == 10) memcpy(noise, g_avg, sizeof(g_avg));                                  // SS:189-193
-    memcpy(g_est_keep, in, sizeof(g_est_keep));                                           // SS:195
+    if (iter == 10) memcpy(noise, g_avg, sizeof(double) * N);                             // SS:189-193
+    memcpy(g_est_keep, in, sizeof(short) * n);                                            // SS:195
 }
 
 static bool denoise_one(int mode, short *in, double *noise, short *out, int n)
 {
-    if (n != 512) { fprintf(stderr, "SpectralSubtraction/WienerFiltering: iFrameCount must be 512\n"); abort(); }
+    frame_count("SpectralSubtraction/WienerFiltering", n);
     jdsp_ctx *ctx = JeicybooContext();
-    if (!g_dn[mode]) CK(jdsp_denoise_create(ctx, mode, &g_dn[mode]));
+    if (!g_dn[mode]) CK(jdsp_denoise_create_cfg(ctx, mode, 2 * n, n, &g_dn[mode]));
     long n_out = 0;
     short tmp[512];
     CK(jdsp_denoise_apply(g_dn[mode], in, 1, noise, tmp, nullptr, &n_out));
-    if (n_out == 1) memcpy(out, tmp, sizeof(tmp));
+    if (n_out == 1) memcpy(out, tmp, sizeof(short) * n);
     return n_out == 1;                                                                    // SS:260-263
 }
 

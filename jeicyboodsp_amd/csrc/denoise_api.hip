@@ -207,6 +207,7 @@ int jdsp_denoise_process_dev(jdsp_denoise *h, const int16_t *pcm_dev, long n_blo
         h->cur ^= 1;
         h->calls += n_blocks;
         h->last_blocks = n_blocks;
+        h->last_trace_valid = h->opt_vad_trace;
         return JDSP_OK;
     }
     if (jdsp::launch_vad(s, pcm_dev, n_blocks, h->w_hi, 1, h->flags, h->opt_vad_trace ? h->dbg_energy : nullptr,
@@ -221,6 +222,7 @@ int jdsp_denoise_process_dev(jdsp_denoise *h, const int16_t *pcm_dev, long n_blo
     h->cur ^= 1;
     h->calls += n_blocks;
     h->last_blocks = n_blocks;
+    h->last_trace_valid = h->opt_vad_trace;
     return JDSP_OK;
 }
 
@@ -267,7 +269,6 @@ int jdsp_denoise_apply(jdsp_denoise *h, const int16_t *pcm_host, long n_blocks, 
     if (!h) return JDSP_EINVAL;
     jdsp_ctx *ctx = h->ctx;
     if (n_blocks < 0 || !noise_host) return fail(ctx, JDSP_EINVAL, "jdsp_denoise_apply: bad argument");
-    if (h->n_fft != 1024) return fail(ctx, JDSP_EINVAL, "jdsp_denoise_apply: 1024-point streams only");
     const long n_out = jdsp_denoise_blocks_out(h, n_blocks);
     if (n_out_blocks) *n_out_blocks = n_out;
     if (n_blocks == 0) return JDSP_OK;
@@ -276,8 +277,9 @@ int jdsp_denoise_apply(jdsp_denoise *h, const int16_t *pcm_host, long n_blocks, 
     int rc = jdsp_denoise_reserve(h, n_blocks);
     if (rc) return rc;
     float row[1024];
-    for (int i = 0; i < 1024; i++) row[i] = (float)noise_host[i];
-    const size_t in_b = (size_t)n_blocks * 1024, out_b = (size_t)(n_out > 0 ? n_out : 1) * 1024;
+    for (int i = 0; i < h->n_fft; i++) row[i] = (float)noise_host[i];          // pdEstimatedNoiseSpec[FFT_PROCESSING_SIZE]
+    const size_t blk_b = (size_t)h->block * sizeof(int16_t);
+    const size_t in_b = (size_t)n_blocks * blk_b, out_b = (size_t)(n_out > 0 ? n_out : 1) * blk_b;
     int16_t *d_in = nullptr, *d_out = nullptr;
     float *d_pre = nullptr;
     hipError_t e = hipMalloc((void **)&d_in, in_b);
@@ -286,18 +288,23 @@ int jdsp_denoise_apply(jdsp_denoise *h, const int16_t *pcm_host, long n_blocks, 
     hipStream_t s = ctx->stream;
     jdsp::DenoiseState *st_in = h->st[h->cur], *st_out = h->st[h->cur ^ 1];
     if (e == hipSuccess) e = hipMemcpyAsync(d_in, pcm_host, in_b, hipMemcpyHostToDevice, s);
-    if (e == hipSuccess) e = hipMemcpyAsync(h->rows, row, sizeof(row), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(h->rows, row, sizeof(float) * (size_t)h->n_fft, hipMemcpyHostToDevice, s);
     if (e == hipSuccess) e = hipMemsetAsync(h->ver_base, 0, ((size_t)n_blocks / 64 + 1) * sizeof(int), s);   // every block uses row 0
     if (e == hipSuccess) e = hipMemsetAsync(h->snap_mask, 0, ((size_t)n_blocks / 64 + 1) * sizeof(unsigned long long), s);
     if (e == hipSuccess) e = hipMemcpyAsync(st_out, st_in, sizeof(jdsp::DenoiseState), hipMemcpyDeviceToDevice, s);
     if (e != hipSuccess) rc = fail(ctx, JDSP_EHIP, "jdsp_denoise_apply: staging", e);
-    if (!rc && jdsp::launch_denoise(s, h->mode, h->opt_k, ctx->n_cu, d_in, n_blocks, h->calls, st_in, st_out, h->ver_base,
-                                    h->snap_mask, h->rows, ctx->stft1024_table, d_out, d_pre))
-        rc = fail(ctx, JDSP_EHIP, "denoise launch", hipGetLastError());
-    if (!rc && n_out > 0 && (e = hipMemcpyAsync(out_host, d_out, (size_t)n_out * 1024, hipMemcpyDeviceToHost, s)) != hipSuccess)
+    if (!rc && (h->n_fft == 512
+                    ? jdsp::launch_denoise512(s, h->mode, ctx->n_cu, d_in, n_blocks, h->calls, st_in, st_out, h->ver_base,
+                                              h->snap_mask, h->rows, ctx->stft1024_table, h->win512h, d_out, d_pre)
+                    : jdsp::launch_denoise(s, h->mode, h->opt_k, ctx->n_cu, d_in, n_blocks, h->calls, st_in, st_out, h->ver_base,
+                                           h->snap_mask, h->rows, ctx->stft1024_table, d_out, d_pre))) {
+        const hipError_t le = hipGetLastError();
+        rc = fail(ctx, JDSP_EHIP, "denoise launch", le);
+    }
+    if (!rc && n_out > 0 && (e = hipMemcpyAsync(out_host, d_out, (size_t)n_out * blk_b, hipMemcpyDeviceToHost, s)) != hipSuccess)
         rc = fail(ctx, JDSP_EHIP, "jdsp_denoise_apply: D2H", e);
     if (!rc && n_out > 0 && precast_host &&
-        (e = hipMemcpyAsync(precast_host, d_pre, (size_t)n_out * 2048, hipMemcpyDeviceToHost, s)) != hipSuccess)
+        (e = hipMemcpyAsync(precast_host, d_pre, (size_t)n_out * blk_b * 2, hipMemcpyDeviceToHost, s)) != hipSuccess)
         rc = fail(ctx, JDSP_EHIP, "jdsp_denoise_apply: D2H", e);
     if ((e = hipStreamSynchronize(s)) != hipSuccess && !rc) rc = fail(ctx, JDSP_EHIP, "jdsp_denoise_apply: sync", e);
     if (d_in) (void)hipFree(d_in);
@@ -364,7 +371,6 @@ int jdsp_denoise_shard_vad_dev(jdsp_denoise *h, const int16_t *pcm_ext_dev, long
 {
     if (!h) return JDSP_EINVAL;
     jdsp_ctx *ctx = h->ctx;
-    if (h->n_fft != 1024) return fail(ctx, JDSP_EINVAL, "jdsp_denoise_shard_*: 1024-point streams only");
     if (!(0 <= ext0 && ext0 <= b0 && b0 <= b1 && b1 <= n_total) || (b0 >= 2 ? ext0 != b0 - 2 : ext0 != 0))
         return fail(ctx, JDSP_EINVAL, "jdsp_denoise_shard_vad: need ext0 = max(b0-2, 0) <= b0 <= b1 <= n_total");
     if (b1 > b0 && (!pcm_ext_dev || !flags_own_dev)) return fail(ctx, JDSP_EINVAL, "jdsp_denoise_shard_vad: NULL buffer");
@@ -375,9 +381,13 @@ int jdsp_denoise_shard_vad_dev(jdsp_denoise *h, const int16_t *pcm_ext_dev, long
     rc = jdsp_denoise_reset(h);                       // a sharded run is one fresh global stream
     if (rc) return rc;
     h->sh_ext0 = ext0; h->sh_b0 = b0; h->sh_b1 = b1; h->sh_total = n_total; h->sh_pcm = pcm_ext_dev;
-    if (jdsp::launch_vad(ctx->stream, pcm_ext_dev + (b0 - ext0) * 512, b1 - b0, h->w_hi, 1, flags_own_dev, nullptr,
-                         nullptr))
-        return fail(ctx, JDSP_EHIP, "vad launch", hipGetLastError());
+    if (h->n_fft == 512 ? jdsp::launch_vad256(ctx->stream, pcm_ext_dev + (b0 - ext0) * 256, b1 - b0, h->w_hi256, flags_own_dev,
+                                              nullptr, nullptr)
+                        : jdsp::launch_vad(ctx->stream, pcm_ext_dev + (b0 - ext0) * 512, b1 - b0, h->w_hi, 1, flags_own_dev,
+                                           nullptr, nullptr)) {
+        const hipError_t le = hipGetLastError();
+        return fail(ctx, JDSP_EHIP, "vad launch", le);
+    }
     return JDSP_OK;
 }
 
@@ -391,10 +401,16 @@ int jdsp_denoise_shard_summary_dev(jdsp_denoise *h, const uint8_t *flags_all_dev
     hipStream_t s = ctx->stream;
     if (jdsp::launch_run_plan(s, flags_all_dev, h->sh_total, h->sh_zero_run, nullptr, 10, h->ver_base, h->snap_mask,
                               h->events, h->ev_n, h->plan) ||
-        jdsp::launch_shard_summary(s, h->sh_pcm, h->sh_b1 - h->sh_ext0, h->sh_ext0, h->sh_b0, h->sh_b1, h->events, h->ev_n,
-                                   h->plan, h->ver_base, h->snap_mask, ctx->stft1024_table, h->sh_range, h->acc, h->rows,
-                                   summary_dev))
-        return fail(ctx, JDSP_EHIP, "shard summary launch", hipGetLastError());
+        (h->n_fft == 512
+             ? jdsp::launch_shard_summary512(s, h->sh_pcm, h->sh_b1 - h->sh_ext0, h->sh_ext0, h->sh_b0, h->sh_b1, h->events,
+                                             h->ev_n, h->plan, h->ver_base, h->snap_mask, ctx->stft1024_table, h->win512h,
+                                             h->sh_range, h->acc, h->rows, summary_dev)
+             : jdsp::launch_shard_summary(s, h->sh_pcm, h->sh_b1 - h->sh_ext0, h->sh_ext0, h->sh_b0, h->sh_b1, h->events,
+                                          h->ev_n, h->plan, h->ver_base, h->snap_mask, ctx->stft1024_table, h->sh_range,
+                                          h->acc, h->rows, summary_dev))) {
+        const hipError_t le = hipGetLastError();
+        return fail(ctx, JDSP_EHIP, "shard summary launch", le);
+    }
     return JDSP_OK;
 }
 
@@ -405,9 +421,13 @@ int jdsp_denoise_shard_rows_dev(jdsp_denoise *h, const float *summaries_all_dev,
     if (!summaries_all_dev || !last_dev || world < 1 || rank < 0 || rank >= world)
         return fail(ctx, JDSP_EINVAL, "jdsp_denoise_shard_rows: bad argument");
     JDSP_HIP(ctx, hipSetDevice(ctx->device));
-    if (jdsp::launch_shard_rows(ctx->stream, summaries_all_dev, rank, h->sh_b0, h->sh_b1, h->plan, h->sh_range, h->acc,
-                                h->sh_a_in, h->rows, last_dev))
-        return fail(ctx, JDSP_EHIP, "shard rows launch", hipGetLastError());
+    if (h->n_fft == 512 ? jdsp::launch_shard_rows512(ctx->stream, summaries_all_dev, rank, h->sh_b0, h->sh_b1, h->plan,
+                                                     h->sh_range, h->acc, h->sh_a_in, h->rows, last_dev)
+                        : jdsp::launch_shard_rows(ctx->stream, summaries_all_dev, rank, h->sh_b0, h->sh_b1, h->plan,
+                                                  h->sh_range, h->acc, h->sh_a_in, h->rows, last_dev)) {
+        const hipError_t le = hipGetLastError();
+        return fail(ctx, JDSP_EHIP, "shard rows launch", le);
+    }
     return JDSP_OK;
 }
 
@@ -430,7 +450,10 @@ int jdsp_denoise_shard_finish_dev(jdsp_denoise *h, const float *last_all_dev, in
     if ((uintptr_t)out_dev & 15u) return fail(ctx, JDSP_EINVAL, "jdsp_denoise_shard_finish: out must be 16-byte aligned");
     JDSP_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
-    if (jdsp::launch_shard_row0(s, last_all_dev, rank, h->rows)) return fail(ctx, JDSP_EHIP, "row0 launch", hipGetLastError());
+    if (h->n_fft == 512 ? jdsp::launch_shard_row0_512(s, last_all_dev, rank, h->rows) : jdsp::launch_shard_row0(s, last_all_dev, rank, h->rows)) {
+        const hipError_t le = hipGetLastError();
+        return fail(ctx, JDSP_EHIP, "row0 launch", le);
+    }
     if (n_out > 0) {
         jdsp::DenoiseShard sh;
         sh.ver_block_off = h->sh_ext0;
@@ -439,10 +462,16 @@ int jdsp_denoise_shard_finish_dev(jdsp_denoise *h, const float *last_all_dev, in
         sh.emit_from = lo - h->sh_ext0;
         sh.emit_to = h->sh_b1 - h->sh_ext0;
         // fresh state: the two halo blocks in front of the shard rebuild the overlap tail
-        if (jdsp::launch_denoise(s, h->mode, h->opt_k, ctx->n_cu, h->sh_pcm, h->sh_b1 - h->sh_ext0, h->sh_ext0, h->st[h->cur],
-                                 h->st[h->cur ^ 1], h->ver_base, h->snap_mask, h->rows, ctx->stft1024_table, out_dev,
-                                 precast_dev, &sh))
-            return fail(ctx, JDSP_EHIP, "denoise launch", hipGetLastError());
+        if (h->n_fft == 512
+                ? jdsp::launch_denoise512(s, h->mode, ctx->n_cu, h->sh_pcm, h->sh_b1 - h->sh_ext0, h->sh_ext0, h->st[h->cur],
+                                          h->st[h->cur ^ 1], h->ver_base, h->snap_mask, h->rows, ctx->stft1024_table,
+                                          h->win512h, out_dev, precast_dev, &sh)
+                : jdsp::launch_denoise(s, h->mode, h->opt_k, ctx->n_cu, h->sh_pcm, h->sh_b1 - h->sh_ext0, h->sh_ext0,
+                                       h->st[h->cur], h->st[h->cur ^ 1], h->ver_base, h->snap_mask, h->rows,
+                                       ctx->stft1024_table, out_dev, precast_dev, &sh)) {
+            const hipError_t le = hipGetLastError();
+            return fail(ctx, JDSP_EHIP, "denoise launch", le);
+        }
     }
     return JDSP_OK;
 }
@@ -463,7 +492,7 @@ int jdsp_denoise_vad_trace(jdsp_denoise *h, long n, uint8_t *voice_host, int64_t
     if (!h) return JDSP_EINVAL;
     jdsp_ctx *ctx = h->ctx;
     if (n < 0 || n > h->last_blocks) return fail(ctx, JDSP_EINVAL, "jdsp_denoise_vad_trace: n exceeds the last call");
-    if ((energy_sum_host || zcr_host) && !h->opt_vad_trace)
+    if ((energy_sum_host || zcr_host) && !h->last_trace_valid)
         return fail(ctx, JDSP_EINVAL, "jdsp_denoise_vad_trace: energies / ZCR are kept only with set_option(\"vad_trace\", 1) before the call");
     if (n == 0) return JDSP_OK;
     if (voice_host) JDSP_HIP(ctx, hipMemcpyAsync(voice_host, h->flags, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));

@@ -1212,7 +1212,9 @@ int launch_denoise(hipStream_t s, int mode, int k_opt, int n_cu, const short *pc
         long waves = (n_blocks + 3) / 4;
         if (waves > slots) waves = slots;
         long run = (n_blocks + waves - 1) / waves;
-        if (const char *e = getenv("JDSP_DENOISE_RUN")) run = atol(e) > 0 ? atol(e) : run;      // tuning only
+#ifdef JDSP_DENOISE_RUN_BLOCKS
+        run = JDSP_DENOISE_RUN_BLOCKS;                             // tools/build_variant.sh: run-length sweeps only
+#endif
         waves = (n_blocks + run - 1) / run;
         const long grid = (waves + 7) / 8 * 8;
         if (mode == 0)
@@ -1295,11 +1297,15 @@ __global__ __launch_bounds__(64) void noise_accum512_kernel(const short *__restr
                                                             const unsigned long long *__restrict__ snap_mask,
                                                             const float2 *__restrict__ table,
                                                             const float *__restrict__ win512, NoiseAccum acc,
-                                                            float *__restrict__ noise_rows, int latch_run)
+                                                            float *__restrict__ noise_rows, int latch_run,
+                                                            const int *__restrict__ range, long ext0)
 {
+    // range / ext0: a sharded run's slice of the event list and the global index of pcm's first block, as in
+    // noise_accum_kernel (st_in is then NULL: a rank's events never reach back past its halo)
     __shared__ __attribute__((aligned(16))) float2 lds[kWaveLdsComplex];
     const int lane = threadIdx.x;
-    const int n_events = plan->n_events;
+    const int e_base = range ? range[0] : 0, row_off = range ? range[2] : 0;
+    const int n_events = range ? range[1] - range[0] : plan->n_events;
     const ChunkGeom cg = chunk_geom(n_events, (int)gridDim.x);
     const int chunk = blockIdx.x;
     if (chunk >= cg.n_chunks) return;
@@ -1322,21 +1328,21 @@ __global__ __launch_bounds__(64) void noise_accum512_kernel(const short *__restr
         if (lane == 0) row[256] = b256;
     };
     auto step = [&](const float (&m)[4], float m256, int e) {
-        const int n = ev_n[e];
+        const int n = ev_n[e_base + e];
         const float h = n >= 3 ? 0.5f : 1.0f;                    // SS:182-187
 #pragma unroll
         for (int q = 0; q < 4; q++) b[q] = (b[q] + m[q]) * h;
         b256 = (b256 + m256) * h;
         alpha *= h;
         if (n == latch_run) {                                    // SS:189-193
-            const int row = version_of(ver_base, snap_mask, events[e]);
+            const int row = version_of(ver_base, snap_mask, events[e_base + e]) - row_off;
             put(noise_rows + (size_t)row * 1024);
             if (lane == 0) { acc.lat_alpha[row] = alpha; acc.lat_chunk[row] = chunk; }
         }
     };
     for (int e = e0; e < e1; e += 2) {
         const int ea = e, eb = e + 1 < e1 ? e + 1 : e;
-        const long sa = ((long)events[ea] - 1) * 256, sb = ((long)events[eb] - 1) * 256;   // [previous block, block] (SS:165-170)
+        const long sa = ((long)events[e_base + ea] - ext0 - 1) * 256, sb = ((long)events[e_base + eb] - ext0 - 1) * 256;   // [previous block, block] (SS:165-170)
         float xa[8], xb[8];
 #pragma unroll
         for (int r = 0; r < 8; r++) {
@@ -1689,24 +1695,60 @@ int launch_noise_estimate512(hipStream_t s, const short *pcm, long n_blocks, con
     const int grid = n_blocks < kNoiseChunks ? (int)(n_blocks > 0 ? n_blocks : 1) : kNoiseChunks;
     if (n_blocks > 0)
         hipLaunchKernelGGL(noise_accum512_kernel, dim3((unsigned)grid), dim3(64), 0, s, pcm, n_blocks, st_in, events, ev_n,
-                           plan, ver_base, snap_mask, table, win512, acc, noise_rows, 10);
+                           plan, ver_base, snap_mask, table, win512, acc, noise_rows, 10, (const int *)nullptr, 0L);
     // bins 0..511 only (rows keep the 1024-float pitch of the 1024-point path)
     hipLaunchKernelGGL(noise_combine_kernel, dim3(512 / kCombineBins), dim3(1024), 0, s, plan, st_in, st_out, acc, noise_rows, grid,
                        (const int *)nullptr, (const float *)nullptr, (float *)nullptr, (float *)nullptr, 1);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
+// sharded runs on 512-point frames: launch_shard_summary / launch_shard_rows with the 512-point accumulate kernel and
+// the combine kernel over bins 0..511 (rows and summaries keep the 1024-float pitch; bins 512.. are never read)
+int launch_shard_summary512(hipStream_t s, const short *pcm_ext, long n_ext, long ext0, long b0, long b1,
+                            const int *events, const int *ev_n, const DenoisePlan *plan, const int *ver_base,
+                            const unsigned long long *snap_mask, const float2 *table, const float *win512, int *range,
+                            const NoiseAccum &acc, float *rows, float *summary)
+{
+    hipLaunchKernelGGL(event_range_kernel, dim3(1), dim3(64), 0, s, events, plan, ver_base, snap_mask, b0, b1, range);
+    const int grid = shard_accum_grid(b1 - b0);
+    hipLaunchKernelGGL(noise_accum512_kernel, dim3((unsigned)grid), dim3(64), 0, s, pcm_ext, n_ext, (const DenoiseState *)nullptr,
+                       events, ev_n, plan, ver_base, snap_mask, table, win512, acc, rows, 10, (const int *)range, ext0);
+    hipLaunchKernelGGL(noise_combine_kernel, dim3(512 / kCombineBins), dim3(1024), 0, s, plan, (const DenoiseState *)nullptr,
+                       (DenoiseState *)nullptr, acc, rows, grid, (const int *)range, (const float *)nullptr, summary,
+                       (float *)nullptr, 0);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+int launch_shard_rows512(hipStream_t s, const float *summaries_all, int rank, long b0, long b1, const DenoisePlan *plan,
+                         const int *range, const NoiseAccum &acc, float *a_in, float *rows, float *last)
+{
+    hipLaunchKernelGGL(fold_summaries_kernel, dim3(2), dim3(256), 0, s, summaries_all, rank, a_in);
+    hipLaunchKernelGGL(noise_combine_kernel, dim3(512 / kCombineBins), dim3(1024), 0, s, plan, (const DenoiseState *)nullptr,
+                       (DenoiseState *)nullptr, acc, rows, shard_accum_grid(b1 - b0), range, (const float *)a_in,
+                       (float *)nullptr, last, 1);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+int launch_shard_row0_512(hipStream_t s, const float *last_all, int rank, float *rows)
+{
+    hipLaunchKernelGGL(select_row0_kernel, dim3(2), dim3(256), 0, s, last_all, rank, rows);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 int launch_denoise512(hipStream_t s, int mode, int n_cu, const short *pcm, long n_blocks, long calls_before,
                       const DenoiseState *st_in, DenoiseState *st_out, const int *ver_base,
                       const unsigned long long *snap_mask, const float *noise_rows, const float2 *table,
-                      const float *win512, short *out, float *precast)
+                      const float *win512, short *out, float *precast, const DenoiseShard *shard)
 {
     if (n_blocks <= 0) return 0;
     DenoiseShard sh;
-    sh.ver_block_off = 0;
-    sh.ver_row_off = nullptr;
-    sh.emit_from = calls_before >= 2 ? 0 : 2 - calls_before;
-    sh.emit_to = n_blocks;
+    if (shard) sh = *shard;
+    else {
+        sh.ver_block_off = 0;
+        sh.ver_row_off = nullptr;
+        sh.emit_from = calls_before >= 2 ? 0 : 2 - calls_before;
+        sh.emit_to = n_blocks;
+    }
 #ifndef JDSP_DENOISE512_RUN
 #define JDSP_DENOISE512_RUN 1
 #endif

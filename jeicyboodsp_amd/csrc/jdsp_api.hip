@@ -184,7 +184,7 @@ int jdsp_set_option(jdsp_ctx *ctx, const char *name, long value)
         return JDSP_OK;
     }
     if (!strcmp(name, "stft.read_pass")) {
-        if (value < -1 || value > 2) return fail(ctx, JDSP_EINVAL, "stft.read_pass: -1 (auto), 0, 1 or 2 (the pass alone)");
+        if (value < -1 || value > 1) return fail(ctx, JDSP_EINVAL, "stft.read_pass: -1 (auto), 0 or 1");
         ctx->opt_stft_read_pass = (int)value;
         return JDSP_OK;
     }

@@ -151,7 +151,14 @@ int launch_noise_estimate512(hipStream_t s, const short *pcm, long n_blocks, con
 int launch_denoise512(hipStream_t s, int mode, int n_cu, const short *pcm, long n_blocks, long calls_before,
                       const DenoiseState *st_in, DenoiseState *st_out, const int *ver_base,
                       const unsigned long long *snap_mask, const float *noise_rows, const float2 *table,
-                      const float *win512, short *out, float *precast);
+                      const float *win512, short *out, float *precast, const DenoiseShard *shard = nullptr);
+int launch_shard_summary512(hipStream_t s, const short *pcm_ext, long n_ext, long ext0, long b0, long b1,
+                            const int *events, const int *ev_n, const DenoisePlan *plan, const int *ver_base,
+                            const unsigned long long *snap_mask, const float2 *table, const float *win512, int *range,
+                            const NoiseAccum &acc, float *rows, float *summary);
+int launch_shard_rows512(hipStream_t s, const float *summaries_all, int rank, long b0, long b1, const DenoisePlan *plan,
+                         const int *range, const NoiseAccum &acc, float *a_in, float *rows, float *last);
+int launch_shard_row0_512(hipStream_t s, const float *last_all, int rank, float *rows);
 int launch_run_plan(hipStream_t s, const unsigned char *flags, long n_blocks, const int *run_len_in, int *run_len_out,
                     int latch_run, int *ver_base, unsigned long long *snap_mask, int *events, int *ev_n,
                     DenoisePlan *plan);
@@ -272,6 +279,7 @@ struct jdsp_denoise {
     long last_blocks = 0;
     int opt_k = 0;
     int opt_vad_trace = 0;                // 1: keep every block's energy sum and ZCR for jdsp_denoise_vad_trace (slower VAD kernel)
+    int last_trace_valid = 0;             // the option's value when the last call ran: what jdsp_denoise_vad_trace may hand out
     int n_fft = 1024, block = 512;        // FFT_PROCESSING_SIZE, BLOCK_LEN = KEEP_LEN (SS:53-55); 512 / 256 also built
     double *w_hi256 = nullptr;            // 512-point frames: second half of the FP64 Hamming(512) (VAD)
     float *win512h = nullptr;             // 512-point frames: 0.5 * Hamming(512), natural order

@@ -159,7 +159,7 @@ int jdsp_mfcc_melfilterbank(jdsp_mfcc *h, const double *abs_host, long n_rows, d
         return rc;
     hipLaunchKernelGGL(jdsp::mel_filterbank_f64_kernel, dim3((unsigned)n_rows), dim3(64), 0, ctx->stream, (const double *)s.d[0],
                        n_rows, NB, C, h->stage_fi, h->stage_fb, (double *)s.d[1]);
-    if (hipGetLastError() != hipSuccess) return fail(ctx, JDSP_EHIP, "mel filterbank launch", hipGetLastError());
+    if (const hipError_t le = hipGetLastError(); le != hipSuccess) return fail(ctx, JDSP_EHIP, "mel filterbank launch", le);
     return s.down(1, mel_host, sizeof(double) * (size_t)n_rows * C);
 }
 
@@ -180,7 +180,7 @@ int jdsp_mfcc_dct(jdsp_mfcc *h, const double *mel_host, long n_rows, double *cep
         return rc;
     hipLaunchKernelGGL(jdsp::dct_f64_kernel, dim3((unsigned)n_rows), dim3(32), 0, ctx->stream, (const double *)s.d[0], n_rows, C,
                        NC, sqrt(2.0 / C), h->stage_cos, (double *)s.d[1]);
-    if (hipGetLastError() != hipSuccess) return fail(ctx, JDSP_EHIP, "dct launch", hipGetLastError());
+    if (const hipError_t le = hipGetLastError(); le != hipSuccess) return fail(ctx, JDSP_EHIP, "dct launch", le);
     return s.down(1, cep_inout_host, sizeof(double) * (size_t)n_rows * NC);
 }
 
@@ -199,7 +199,7 @@ int jdsp_mfcc_liftering(jdsp_mfcc *h, double *cep_inout_host, long n_rows)
     if ((rc = s.up(0, cep_inout_host, sizeof(double) * (size_t)n_rows * NC))) return rc;
     hipLaunchKernelGGL(jdsp::lifter_f64_kernel, dim3((unsigned)n_rows), dim3(32), 0, ctx->stream, (double *)s.d[0], n_rows, NC,
                        h->stage_lift);
-    if (hipGetLastError() != hipSuccess) return fail(ctx, JDSP_EHIP, "lifter launch", hipGetLastError());
+    if (const hipError_t le = hipGetLastError(); le != hipSuccess) return fail(ctx, JDSP_EHIP, "lifter launch", le);
     return s.down(0, cep_inout_host, sizeof(double) * (size_t)n_rows * NC);
 }
 
@@ -227,7 +227,7 @@ int jdsp_gmm_probability(jdsp_ctx *ctx, const double *feats_host, long n, const 
         return rc;
     hipLaunchKernelGGL(jdsp::gmm_probability_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
                        (const double *)s.d[0], n, (const double *)s.d[1], (double *)s.d[2]);
-    if (hipGetLastError() != hipSuccess) return fail(ctx, JDSP_EHIP, "gmm probability launch", hipGetLastError());
+    if (const hipError_t le = hipGetLastError(); le != hipSuccess) return fail(ctx, JDSP_EHIP, "gmm probability launch", le);
     return s.down(2, prob_host, sizeof(double) * (size_t)n);
 }
 

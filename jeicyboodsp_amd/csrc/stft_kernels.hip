@@ -458,12 +458,18 @@ int launch_stft1024(hipStream_t stream, int n_cu, int fpw_opt, const short *pcm,
     if (n_frames <= 0) return 0;
     if (hop == 512 && ((uintptr_t)pcm & 15u) == 0) {
         const bool touch = read_pass > 0 || (read_pass < 0 && n_frames >= kReadPassMinFrames);
-        if (read_pass == 2) {                                   // the read pass alone (tools/prefetch_probe.py)
+#ifdef JDSP_PROBE_READ_PASS_ALONE
+        // timing-only build (tools/build_variant.sh -DJDSP_PROBE_READ_PASS_ALONE, tools/prefetch_probe.py): "stft.read_pass" = 1
+        // issues the read pass and NO transform -- spectra are not written.  Never part of the shipped library.
+        if (read_pass == 1) {
             for (long f0 = 0; f0 < n_frames; f0 += kReadPassSlabFrames) {
                 const long nf = n_frames - f0 < kReadPassSlabFrames ? n_frames - f0 : kReadPassSlabFrames;
                 if (launch_pcm_touch(stream, n_cu, touch_wg_per_cu, pcm + f0 * 512, 512 * (nf + 1))) return -1;
             }
-        } else if (!touch) {
+            return hipGetLastError() == hipSuccess ? 0 : -1;
+        }
+#endif
+        if (!touch) {
             launch_hop512_any(stream, fpw_opt, pcm, n_frames, spec, table);
         } else {
             // slab by slab, so that a slab's PCM (64 MiB) is a quarter of the Infinity Cache whatever the batch is

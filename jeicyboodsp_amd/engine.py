@@ -337,13 +337,28 @@ class Denoiser:
     def shard_finish(self, last_all, world, rank, want_precast=False):
         import torch
         n_out = L.jdsp_denoise_shard_blocks_out(self._h)
-        out = torch.empty(max(n_out, 1) * 512, dtype=torch.int16, device=last_all.device)
-        pre = torch.empty(max(n_out, 1) * 512, dtype=torch.float32, device=last_all.device) if want_precast else None
+        B = self.block
+        out = torch.empty(max(n_out, 1) * B, dtype=torch.int16, device=last_all.device)
+        pre = torch.empty(max(n_out, 1) * B, dtype=torch.float32, device=last_all.device) if want_precast else None
         self.eng._use_torch_stream()
         self.eng._ck(L.jdsp_denoise_shard_finish_dev(self._h, C.c_void_p(last_all.data_ptr()), world, rank,
                                                      C.c_void_p(out.data_ptr()),
                                                      C.c_void_p(pre.data_ptr()) if want_precast else None, None))
-        return (out[: n_out * 512], pre[: n_out * 512]) if want_precast else out[: n_out * 512]
+        return (out[: n_out * B], pre[: n_out * B]) if want_precast else out[: n_out * B]
+
+    def apply(self, pcm, noise, want_precast=False):
+        """SpectralSubtraction / WienerFiltering (SS:201-264 / WF:162-235) over whole blocks with the CALLER's
+        pdEstimatedNoiseSpec (n_fft doubles) instead of the handle's own VAD + estimate (jdsp_denoise_apply; host)."""
+        B = self.block
+        pcm = np.ascontiguousarray(pcm, np.int16)
+        noise = np.ascontiguousarray(noise, np.float64)
+        assert pcm.size % B == 0 and noise.size == self.n_fft
+        nb = pcm.size // B
+        n_out = self.blocks_out(nb)
+        out = np.zeros(max(n_out, 1) * B, np.int16)
+        pre = np.zeros(max(n_out, 1) * B, np.float32) if want_precast else None
+        self.eng._ck(L.jdsp_denoise_apply(self._h, _vp(pcm), nb, _vp(noise), _vp(out), _vp(pre), None))
+        return (out[:n_out * B], pre[:n_out * B]) if want_precast else out[:n_out * B]
 
     def noise(self):
         n = np.zeros(self.n_fft, np.float64)

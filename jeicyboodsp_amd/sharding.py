@@ -142,3 +142,23 @@ def utterance_batch_shard(utt_first, rank, world):
     hi = int(utt_first[first_utt + n_utt])
     local_first = [int(utt_first[first_utt + k]) - lo for k in range(n_utt + 1)]
     return first_utt, n_utt, lo, hi, local_first
+
+
+def mfcc_utterance_shard(utt_sample_first, win_len, hop, rank, world):
+    """MFCC over a batch of utterances packed back to back (BASELINE config 4: "10 000-utterance batch sharded across
+    1/2/4/8 GPUs"): whole utterances per rank, contiguous, balanced by FRAME count; no halo (an utterance is framed on
+    its own, MFCCFeatureExtraction_auto_version1.cpp:68-101 opens one file per utterance), no data-path collective.
+    utt_sample_first: the n_utts + 1 sample offsets of the whole batch (host sequence).
+    Returns (first_utt, n_utt, sample_lo, sample_hi, frame_lo, frame_hi, local_starts): the rank is given samples
+    [sample_lo, sample_hi), computes frames [frame_lo, frame_hi) of the batch's frame list, and local_starts (a numpy
+    int64 array) are its frames' first samples relative to sample_lo -- what jdsp_mfcc_frames_dev takes as frame_start."""
+    import numpy as np
+    offs = np.asarray(utt_sample_first, dtype=np.int64)
+    lens = offs[1:] - offs[:-1]
+    nf = np.where(lens >= win_len, (lens - win_len) // hop + 1, 0)
+    first_utt, n_utt = utterance_shard([int(v) for v in nf], rank, world)
+    frame_first = np.concatenate([[0], np.cumsum(nf)])
+    lo, hi = int(offs[first_utt]), int(offs[first_utt + n_utt])
+    starts = [offs[u] - lo + hop * np.arange(nf[u], dtype=np.int64) for u in range(first_utt, first_utt + n_utt)]
+    local_starts = np.concatenate(starts) if starts else np.zeros(0, np.int64)
+    return first_utt, n_utt, lo, hi, int(frame_first[first_utt]), int(frame_first[first_utt + n_utt]), local_starts

@@ -49,7 +49,7 @@ def test_every_declared_symbol_is_exported(lib):
 
 def test_abi_version_and_null_handling(lib):
     lib.jdsp_abi_version.restype = C.c_int
-    assert lib.jdsp_abi_version() == 1
+    assert lib.jdsp_abi_version() == 2            # include/jdsp.h: JDSP_ABI_VERSION
     lib.jdsp_last_error.restype = C.c_char_p
     for fn in ("jdsp_destroy", "jdsp_denoise_destroy", "jdsp_mfcc_destroy", "jdsp_fastconv_destroy"):
         f = getattr(lib, fn)

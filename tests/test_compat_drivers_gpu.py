@@ -422,3 +422,24 @@ def test_compat_vad_functions_equal_the_compiled_reference(tmp_path, golden_dir)
     assert np.array_equal(g["ss_flags"], g["wf_flags"])
     run("compat_mvdr_selftest", tmp_path / "blocks.raw", tmp_path / "blocks.raw", tmp_path / "bf.bin", "vad")
     assert np.array_equal(np.fromfile(tmp_path / "bf.bin", np.uint8), g["bf_flags"])
+
+
+@pytest.mark.parametrize("what,mode", [("ss", 0), ("wf", 1)])
+def test_compat_denoise_per_block_calls_with_iframecount_256(tmp_path, oracle, what, mode):
+    """The per-block signatures carry iFrameCount (SS:58-60): 256 = the programs with BLOCK_LEN / KEEP_LEN 256 and
+    FFT_PROCESSING_SIZE 512 (BASELINE config 3 as worded), main()'s loop one block per call."""
+    rng = np.random.default_rng(77)
+    n_blocks = 90
+    alt = np.where(np.arange(256) % 2 == 0, 1.0, -1.0)
+    x = rng.normal(0, 3000, n_blocks * 256)
+    for b0, n in ((0, 14), (40, 13)):                                     # sign-alternating quiet stretches: ZCR >= 200
+        x[b0 * 256:(b0 + n) * 256] = (np.abs(rng.normal(0, 45, (n, 256))) + 14.0).ravel() * np.tile(alt, n)
+    pcm = np.clip(np.rint(x), -32768, 32767).astype(np.int16)
+    pcm.tofile(tmp_path / "in.raw")
+    run("compat_selftest", what, tmp_path / "in.raw", tmp_path / "out.bin", 256)
+    got = np.fromfile(tmp_path / "out.bin", np.int16)
+    want, _ = oracle.denoise_stream(mode, pcm, block=256)
+    _, _, flags, noises, _ = oracle.denoise_trace(mode, pcm, block=256)
+    assert len(noises) >= 3 and 0 < flags.sum() < n_blocks                # estimates were latched; both VAD outcomes occur
+    assert got.shape == want.shape == ((n_blocks - 2) * 256,)
+    assert np.abs(got.astype(np.int32) - want.astype(np.int32)).max() <= 1

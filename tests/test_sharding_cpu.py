@@ -117,3 +117,14 @@ def test_utterance_batch_shard_covers_every_utterance_once():
             assert [local[k + 1] - local[k] for k in range(n)] == lens[u0:u0 + n]
             vecs += hi - lo
         assert seen == list(range(97)) and vecs == first[-1]
+
+
+def test_mfcc_utterance_shard_edges():
+    from jeicyboodsp_amd import sharding
+    offs = [0, 1000, 1000, 1300, 5000]                                      # an empty and a too-short utterance (no frames)
+    seen = []
+    for r in range(3):
+        u0, nu, lo, hi, f0, f1, local = sharding.mfcc_utterance_shard(offs, 400, 160, r, 3)
+        seen.append((u0, nu, f0, f1))
+        assert local.size == f1 - f0 and (local.size == 0 or (local.min() >= 0 and local.max() + 400 <= hi - lo))
+    assert seen[0][0] == 0 and sum(s[1] for s in seen) == 4 and seen[-1][3] == 4 + 0 + 0 + 21

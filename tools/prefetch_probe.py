@@ -3,10 +3,14 @@
 
 The headline step is pcm_touch_kernel (64 MiB of PCM streamed into the Infinity Cache, ~9-13 us) followed by the
 transform at the chip's store rate (~88 us).  A pipelined caller knows its next batch: this probe issues the read pass
-of batch n+1 on a second stream (a second context with "stft.read_pass" = 2: the pass alone) while batch n's transform
+of batch n+1 on a second stream (a second context whose STFT entry issues the pass alone) while batch n's transform
 runs with its own pass off, eagerly and in one captured graph of K steps, against the library's default.
 
-    python tools/prefetch_probe.py [--steps 400]
+The pass alone is not something the shipped library does (it would return spectra nobody wrote): it exists in a
+timing-only build.  So:
+
+    tools/build_variant.sh pass_alone -DJDSP_PROBE_READ_PASS_ALONE
+    JDSP_LIB=build/variants/pass_alone.so python tools/prefetch_probe.py [--steps 400]
 """
 import argparse
 import json
@@ -29,7 +33,8 @@ def main():
     a = ap.parse_args()
     eng = jeicyboodsp_amd.Engine(0)
     pre = jeicyboodsp_amd.Engine(0)
-    pre.set_option("stft.read_pass", 2)
+    assert "pass_alone" in os.environ.get("JDSP_LIB", ""), "needs the -DJDSP_PROBE_READ_PASS_ALONE build (see the docstring)"
+    pre.set_option("stft.read_pass", 1)              # in that build: the read pass and no transform
     B, P, K = a.frames, a.buffers, a.steps
     rng = np.random.default_rng(0)
     base = torch.from_numpy(rng.integers(-20000, 20000, 512 * (B + 1)).astype(np.int16)).cuda()
