@@ -36,6 +36,7 @@ sys.path.insert(0, ROOT)
 
 N_FFT, HOP, FRAMES_PER_GPU = 1024, 512, 65536
 BYTES_PER_FRAME = 512 * 2 + 1024 * 8          # 9,216 B algorithmic
+BYTES_PER_FRAME_F64 = 512 * 2 + 1024 * 16     # the same analysis in the reference's FP64: complex128 spectrum
 HBM_PEAK_GBS = 8000.0                         # MI355X_MICROARCH.md: 8.0 TB/s spec
 TRAFFIC_FILE = os.path.join("profiles", "stft_pmc_traffic.json")
 EXIT_STUCK_COLLECTIVE = 3
@@ -52,6 +53,12 @@ def parse_args(argv=None):
     ap.add_argument("--gather", action="store_true", help="time the all_gather of the spectra even with one rank")
     ap.add_argument("--no-gather", action="store_true", help="skip the (separately reported) output all_gather at N > 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fp64-leg", action="store_true",
+                    help="skip roofline.fp64 (the same K steps through jdsp_stft_i16_f64_dev, timed after the reported leg)")
+    ap.add_argument("--workload", choices=["stft", "mfcc10k"], default="stft",
+                    help="stft (default): the headline metric.  mfcc10k: BASELINE config 4 -- the 10,000-utterance MFCC batch "
+                         "(400/160 framing, 512-FFT, 40 mel) sharded by utterance over the ranks (strong scaling); a secondary "
+                         "line, never the headline")
     ap.add_argument("--no-graph", action="store_true", help="time eager launches instead of one hipGraph replay of the K steps")
     ap.add_argument("--spinup-ms", type=float, default=60.0,
                     help="untimed load before the W warmup steps so that the GPU is at its sustained clocks whatever W is "
@@ -288,7 +295,7 @@ def run_rank(args):
     # opens the timed region.  The defaults (W = 500, K = 1000: 48 ms + 96 ms of GPU time) are sized for the
     # GPU's clock management: after an idle period it takes tens of milliseconds of continuous load to
     # reach its sustained clocks (profiles/r01_bench_warmup_sweep.txt).
-    def capture(bufs):
+    def capture(bufs, step=step):
         if args.no_graph:
             return None
         try:
@@ -305,7 +312,7 @@ def run_rank(args):
             print("bench: graph capture failed (%s), timing eager launches" % exc, file=sys.stderr)
             return None
 
-    def timed(bufs, graph):
+    def timed(bufs, graph, step=step):
         for i in range(args.warmup):
             step(i, bufs)
         barrier()
@@ -352,13 +359,30 @@ def run_rank(args):
         eng.set_option("stft.read_pass", -1)
     elapsed, kern_ms = timed(pcms, graph)             # the reported figure: library defaults, input rotated over P buffers
 
+    # The reference computes in FP64 (SS:205-206 fftw_complex): the same K steps through jdsp_stft_i16_f64_dev
+    # (complex128 out, 17,408 algorithmic bytes per frame), AFTER the reported leg so that `value` is untouched.
+    f64 = None
+    if not args.no_fp64_leg:
+        spec = None                                   # 512 MiB back before the 1 GiB of complex128
+        spec64 = torch.empty((B, N_FFT), dtype=torch.complex128, device=dev)
+        def step64(i, bufs):
+            eng.stft_f64(bufs[i % len(bufs)], B, HOP, out=spec64)
+
+        step64(0, pcms)
+        barrier()
+        f64 = timed(pcms, capture(pcms, step64), step64)
+        del spec64
+        spec = torch.empty((B, N_FFT), dtype=torch.complex64, device=dev)
+        eng.stft(pcms[0], B, N_FFT, HOP, out=spec)    # the gather below moves real spectra
+
     # whole-job timing: MAX over ranks of the wall clock and of the per-launch duration
-    t = torch.tensor([elapsed, kern_ms] + (list(warm) + list(cold0) if warm else [0.0] * 4), dtype=torch.float64, device=dev)
+    t = torch.tensor([elapsed, kern_ms] + (list(warm) + list(cold0) if warm else [0.0] * 4) + (list(f64) if f64 else [0.0] * 2),
+                     dtype=torch.float64, device=dev)
     if dist is not None:
         tt = t.cpu() if args.backend == "gloo" else t
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         t = tt
-    elapsed, kern_ms, warm_elapsed, warm_kern_ms, cold0_elapsed, cold0_kern_ms = (float(x) for x in t)
+    elapsed, kern_ms, warm_elapsed, warm_kern_ms, cold0_elapsed, cold0_kern_ms, f64_elapsed, f64_kern_ms = (float(x) for x in t)
 
     # The only collective of the path: gathering the spectra (RCCL all_gather over xGMI).  Timed
     # AFTER and OUTSIDE the timed region, reported separately, never part of `value` (SURVEY §8e asks for
@@ -449,6 +473,15 @@ def run_rank(args):
             line["roofline"]["cold_input_without_read_pass"] = {
                 "kernel_ms": cold0_kern_ms, "achieved": c_ach, "frac": c_ach / HBM_PEAK_GBS, "value": frames_total / cold0_elapsed,
                 "note": "input rotated like the reported figure, read pass off: what stft1024_hop512_kernel<2> alone does with PCM in HBM"}
+        if f64 is not None:
+            alg64 = BYTES_PER_FRAME_F64 * B
+            a64 = alg64 / (f64_kern_ms * 1e-3) / 1e9
+            line["roofline"]["fp64"] = {
+                "kernel_ms": f64_kern_ms, "achieved": a64, "frac": a64 / HBM_PEAK_GBS, "unit": "GB/s",
+                "value": frames_total / f64_elapsed, "algorithmic_bytes_per_launch": alg64, "dtype": "f64",
+                "kernel": "stft1024_f64_v2_kernel behind pcm_touch_kernel (jdsp_stft_i16_f64_dev): the reference's own "
+                          "arithmetic (FP64 window, transform and split; complex128 full spectrum, 17,408 B per frame)",
+                "note": "same K steps, same rotated input, timed after the reported leg; never part of `value`"}
         if gather_ms is not None:
             line["gather"] = {"ms": gather_ms, "bytes_per_rank": B * N_FFT * 8, "transport": gather_note,
                               "frames_per_s_including_gather": float(B) * world / (elapsed / args.steps + gather_ms * 1e-3)}
@@ -472,6 +505,120 @@ def run_rank(args):
     return 0
 
 
+# ------------------------------------------------------------------ BASELINE config 4 (secondary line)
+MFCC_KW = dict(win_len=400, hop=160, n_fft=512, n_chan=40, n_cep=13, half_rate=8000.0)
+MFCC_BYTES_PER_FRAME = 160 * 2 + 13 * 8       # hop new samples in, n_cep doubles out
+
+
+def mfcc10k_batch():
+    """The 10,000-utterance ragged batch (1-6 s at 16 kHz, packed back to back): sample offsets and a 4 M-sample
+    noise table the PCM is tiled from (seeded: every rank builds the same batch and keeps its own shard)."""
+    import numpy as np
+    rng = np.random.default_rng(2024)
+    lens = rng.integers(16000, 6 * 16000 + 1, 10000)
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    table = np.clip(np.rint(rng.normal(0, 3000, 1 << 22)), -32768, 32767).astype(np.int16)
+    return offs, table
+
+
+def run_rank_mfcc(args):
+    """`--workload mfcc10k`: whole utterances per rank (sharding.mfcc_utterance_shard), no halo, no collective on the
+    data path; STRONG scaling (the batch is fixed, N ranks split it).  value = frames of the whole batch per second."""
+    import numpy as np
+    import torch
+    import jeicyboodsp_amd
+    from jeicyboodsp_amd import sharding
+
+    dist, rank, world, local_rank = init_dist(args)
+    assert world == args.gpus, "world size %d != --gpus %d" % (world, args.gpus)
+    n_dev = torch.cuda.device_count()
+    assert n_dev >= 1, "bench.py needs a GPU (no CPU fallback)"
+    dev_index = local_rank % n_dev
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    eng = jeicyboodsp_amd.Engine(dev_index)
+    offs, table = mfcc10k_batch()
+    u0, nu, lo, hi, f0, f1, local = sharding.mfcc_utterance_shard(offs, MFCC_KW["win_len"], MFCC_KW["hop"], rank, world)
+    total_frames = sum(sharding.mfcc_utterance_shard(offs, MFCC_KW["win_len"], MFCC_KW["hop"], r, world)[5] -
+                       sharding.mfcc_utterance_shard(offs, MFCC_KW["win_len"], MFCC_KW["hop"], r, world)[4] for r in range(world))
+    T = table.size
+    pcm = np.tile(table, (hi - lo) // T + 2)[lo % T: lo % T + (hi - lo)]
+    d_pcm = torch.from_numpy(np.ascontiguousarray(pcm)).to(dev)
+    d_st = torch.from_numpy(local).to(dev)
+    nf = int(local.size)
+    feats = torch.empty((max(nf, 1), MFCC_KW["n_cep"]), dtype=torch.float64, device=dev)
+    m = eng.mfcc(**MFCC_KW)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step():
+        if nf:
+            m.frames(d_pcm, nf, frame_start=d_st, out=feats)
+
+    step()
+    barrier()
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(args.steps):
+        step()
+    e1.record()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kern_ms = e0.elapsed_time(e1) / max(args.steps, 1)
+    t = torch.tensor([elapsed, kern_ms], dtype=torch.float64, device=dev)
+    if dist is not None:
+        tt = t.cpu() if args.backend == "gloo" else t
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        t = tt
+    elapsed, kern_ms = float(t[0]), float(t[1])
+    if rank == 0:
+        alg = MFCC_BYTES_PER_FRAME * nf
+        ach = alg / (kern_ms * 1e-3) / 1e9
+        line = {"metric": "MFCC frames/s (25 ms / 10 ms framing, 512-FFT, 40 mel + DCT; 10,000-utterance batch)",
+                "value": float(total_frames) * args.steps / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+                "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+                "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": "MFCC 400/160 framing, 512-FFT, 40 mel, 13 cepstra (FP64 out); 10,000 ragged utterances "
+                                       "(1-6 s at 16 kHz, %d frames), int16 PCM in HBM -> double[13] vectors in HBM" % total_frames,
+                           "parallelism": "utterance-sharded x%d (balanced by frame count), no collective" % world,
+                           "frames_rank0": nf, "utterances_rank0": nu, "launch": "eager",
+                           "backend": args.backend if dist is not None else None},
+                "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                             "traffic": None, "kernel": "mfcc512_pair_kernel (+ mfcc_kernel for the listed unequal pairs)",
+                             "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": alg,
+                             "note": "424 B per frame against ~28 kflop: this chain is VALU/LDS-issue-bound, the HBM fraction "
+                                     "is reported for completeness (DESIGN.md 3.6); rank 0's launch"}}
+        if not args.no_cpu_baseline and world == 1:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import oracle_lib
+            orc = oracle_lib.load_oracle()
+            ocfg = orc.mfcc_cfg(n_bins=256, **MFCC_KW)
+            done, t1 = 0, time.perf_counter()
+            u = 0
+            while time.perf_counter() - t1 < 10.0:
+                n = int((offs[u + 1] - offs[u] - 400) // 160 + 1)
+                orc.mfcc_frames(ocfg, pcm[offs[u] - lo: offs[u + 1] - lo], n)
+                done += n
+                u += 1
+            line["cpu_baseline"] = {"value": done / (time.perf_counter() - t1), "unit": "frames/s", "cores": 1, "kind": "port",
+                                    "sample": "the batch's first %d utterances (%d frames), FP64 oracle, single thread" % (u, done)}
+        print(json.dumps(line), flush=True)
+    m.close()
+    eng.close()
+    if dist is not None:
+        if not guarded(lambda: dist.barrier(async_op=True), 60.0):
+            os._exit(EXIT_STUCK_COLLECTIVE)
+        dist.destroy_process_group()
+    return 0
+
+
 def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
     args = parse_args(argv)
@@ -480,6 +627,8 @@ def main(argv=None):
         return launch_ranks(args, argv)
     if args.launcher_selftest:
         return selftest_rank(args)
+    if args.workload == "mfcc10k":
+        return run_rank_mfcc(args)
     return run_rank(args)
 
 

@@ -78,9 +78,10 @@ int jdsp_use_own_stream(jdsp_ctx *ctx);
  *                           that HBM sees a read stream and then a write stream instead of their 1 : 8 mix
  *                           (65,536 frames whose PCM is in HBM: 98 us against 147 us; PCM that is already
  *                           cache-resident pays 9 us for nothing -- 0 turns the pass off).  Results are identical.
- *                           2 = the pass alone, no transform (measurement only: tools/prefetch_probe.py issues the
- *                           next batch's pass under the current transform from a second context -- 115-120 us
- *                           per step against 98.5 one after the other, so there is no prefetch entry).
+ *                           The FP64 analysis (jdsp_stft_i16_f64*) takes the same pass.
+ *   "stft.f64_kernel"       0 (default): the FP64 analysis at four waves per SIMD (twiddles as powers of one value
+ *                           per family); 1: round 2's kernel (all tables in registers, two waves per SIMD) -- A/B
+ *   "stft.f64_frames_per_wave"  frames one wave of the FP64 analysis walks (0 = one round of resident waves)
  *   "stft.window"           window of jdsp_stft_*: 0 = the reference's Hamming
  *                           0.54-0.46cos(2*3.141592*i/(n-1)) (default), 1 = Hann 0.5-0.5cos(same).
  *                           The denoise / MFCC / pitch chains always use what the reference uses. */

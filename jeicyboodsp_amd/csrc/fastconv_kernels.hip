@@ -187,6 +187,12 @@ __device__ __forceinline__ void constexpr_row(int d, int odd, short *obase, unsi
 #ifndef JDSP_CONV1024_MINWAVES
 #define JDSP_CONV1024_MINWAVES 3
 #endif
+#ifndef JDSP_CONV1024_X2
+#define JDSP_CONV1024_X2 1          // 1: a filter pair's two inverse transforms staggered in one wave; 0: one after the other (round 2)
+#endif
+#if JDSP_CONV1024_X2 && !JDSP_CONV1024_H_IN_REGS
+#error "JDSP_CONV1024_X2 takes the filter spectra from registers"
+#endif
 template <int NF, int N0, int BLOCK>
 __global__ __launch_bounds__(64, JDSP_CONV1024_MINWAVES) void fastconv1024_pairs_kernel(ConvStream s, long n_out_blocks, int first_block,
                                                                 const float2 *__restrict__ Hall,
@@ -194,7 +200,8 @@ __global__ __launch_bounds__(64, JDSP_CONV1024_MINWAVES) void fastconv1024_pairs
                                                                 float *__restrict__ precast, long plane,
                                                                 short *__restrict__ hist_out)
 {
-    __shared__ __attribute__((aligned(16))) float2 lds[kWaveLdsComplex];
+    // NF == 2: the two ears' inverse transforms run staggered in one wave (wave_fft512.h), each in its own scratch
+    __shared__ __attribute__((aligned(16))) float2 lds[(NF == 2 && JDSP_CONV1024_X2) ? 2 * kWaveLdsComplex : kWaveLdsComplex];
     const int lane = threadIdx.x;
     if ((long)blockIdx.x >= n_out_blocks) return;
     if (blockIdx.x == gridDim.x - 1 && hist_out) {
@@ -270,25 +277,51 @@ __global__ __launch_bounds__(64, JDSP_CONV1024_MINWAVES) void fastconv1024_pairs
             lo[d] = cadd(ev, p);
             hi[d] = csub(ev, p);
         }
+        float2 yy[NF][8];
+#if JDSP_CONV1024_X2
+        if (NF == 2) {
+            float2 ret[2][4];
+#pragma unroll
+            for (int f = 0; f < 2; f++)
+#pragma unroll
+                for (int d = 0; d < 5; d++) {
+                    const float2 yl = cmul(lo[d], Hlo[f][d]), yh = cmul(hi[d], Hhi[f][d]);       // :150-151
+                    if (d < 4) presplit_inv_pair(yl, yh, pw.w[d], yy[f][d], ret[f][d]);
+                    else yy[f][d] = presplit_inv_reg(yl, yh, pw.w[d]);
+                }
+            float2 *lds_b = lds + (NF == 2 ? kWaveLdsComplex : 0);
+            // both ears' mirror halves go to their owners in one round trip
+#pragma unroll
+            for (int d = 0; d < 4; d++) { lds[512 - lane - 64 * d] = ret[0][d]; lds_b[512 - lane - 64 * d] = ret[1][d]; }
+            wave_lds_fence();
+#pragma unroll
+            for (int d = 5; d < 8; d++) { yy[0][d] = lds[lane + 64 * d]; yy[NF - 1][d] = lds_b[lane + 64 * d]; }
+            wave_lds_fence();
+            wave_fft512_x2_staggered<true>(yy[0], yy[NF - 1], lds, lds_b, lane, tw);
+        }
+#endif
 #pragma unroll
         for (int f = 0; f < NF; f++) {
-            float2 y[8], ret[4];
+            float2 (&y)[8] = yy[f];
+            if (!(NF == 2 && JDSP_CONV1024_X2)) {
+                float2 ret[4];
 #pragma unroll
-            for (int d = 0; d < 5; d++) {
+                for (int d = 0; d < 5; d++) {
 #if JDSP_CONV1024_H_IN_REGS
-                const float2 yl = cmul(lo[d], Hlo[f][d]), yh = cmul(hi[d], Hhi[f][d]);           // :150-151
+                    const float2 yl = cmul(lo[d], Hlo[f][d]), yh = cmul(hi[d], Hhi[f][d]);           // :150-151
 #else
-                const float2 *H = Hall + (size_t)f * 1024 + lane;         // 16 KB for a filter pair: L1 / L2 hits
-                const float2 yl = cmul(lo[d], H[64 * d]), yh = cmul(hi[d], H[64 * d + 512]);     // :150-151
+                    const float2 *H = Hall + (size_t)f * 1024 + lane;         // 16 KB for a filter pair: L1 / L2 hits
+                    const float2 yl = cmul(lo[d], H[64 * d]), yh = cmul(hi[d], H[64 * d + 512]);     // :150-151
 #endif
-                if (d < 4) presplit_inv_pair(yl, yh, pw.w[d], y[d], ret[d]);
-                else y[d] = presplit_inv_reg(yl, yh, pw.w[d]);
-            }
-            pair_return_lds(ret, lds, lane, y);
+                    if (d < 4) presplit_inv_pair(yl, yh, pw.w[d], y[d], ret[d]);
+                    else y[d] = presplit_inv_reg(yl, yh, pw.w[d]);
+                }
+                pair_return_lds(ret, lds, lane, y);
 #if !(JDSP_CONV_ABLATE & 1)                                            /* 1, timing-only: no inverse transforms */
-            wave_fft512<true>(y, lds, lane, tw);
+                wave_fft512<true>(y, lds, lane, tw);
 #endif
-            wave_lds_fence();
+                wave_lds_fence();
+            }
             short *obase = out + (size_t)f * plane + e * block - n0;         // obase[n] = where sample n of the segment goes
             const int odd = (int)((reinterpret_cast<uintptr_t>(obase) >> 1) & 1);  // wave-uniform: which pairing is dword-aligned
             unsigned int *p32 = reinterpret_cast<unsigned int *>(obase + 2 * lane + odd);

@@ -306,16 +306,166 @@ __global__ __launch_bounds__(64) void stft1024_f64_kernel(const short *__restric
   }
 }
 
-int launch_stft1024_f64(hipStream_t stream, const short *pcm, long n_frames, long hop, const double *table,
-                        const double2 *tw512, double2 *out)
+// Round 3: the same arithmetic at FOUR waves per SIMD instead of two.  The kernel above keeps 120 VGPRs of loop-
+// invariant tables (7 + 7 transform twiddles, 8 window pairs, 8 split twiddles: 176 registers, two waves per SIMD) and
+// so has two waves per SIMD to hide its loads behind -- loads that queue behind the chip's write stream (stft_kernels.hip,
+// "read pass").  Here only ONE value of each twiddle family stays in registers and the others are its powers, formed
+// per frame (FP64 issue has the slack: ~450 instructions per lane and frame = 48 us per 65,536 frames against a 166 us
+// store floor; +90 for the powers):
+//     pass 1   w512^(lane k)      = (w512^lane)^k                       k = 2..7 by six complex products
+//     pass 2   w512^(8 j c)       = (w64^j)^c,  j = lane & 7            the same chain
+//     split    W1024^(lane + 64d) = W1024^lane * W16^d                  W16^d are literals
+// (a product's rounding is 1e-16: the result moves by < 1e-15 of the frame peak; the tests hold it to 1e-12 of the
+// CPU restatement and 1e-9 of the reference's FFTProcess).  The window stays in registers.  An empty asm on the three base
+// values per frame keeps the compiler from hoisting the powers back out of the loop.  The frame's samples are one
+// dword per lane and row when pcm is 4-byte aligned and hop is even (DW), and the NEXT frame's are requested before
+// this frame's sixteen stores.
+__device__ __forceinline__ void cd_opaque(cd &a) { asm volatile("" : "+v"(a.x), "+v"(a.y)); }
+__device__ __forceinline__ void cd_powers(const cd &b, cd (&p)[8])
+{
+    p[1] = b;
+    p[2] = cd_mul(b, b);
+    p[3] = cd_mul(p[2], b);
+    p[4] = cd_mul(p[2], p[2]);
+    p[5] = cd_mul(p[4], b);
+    p[6] = cd_mul(p[3], p[3]);
+    p[7] = cd_mul(p[4], p[3]);
+}
+
+template <bool DW>
+__global__ __launch_bounds__(64, 4) void stft1024_f64_v2_kernel(const short *__restrict__ pcm, long n_frames, long hop,
+                                                               const double *__restrict__ table,
+                                                               const double2 *__restrict__ tw, double2 *__restrict__ out,
+                                                               int run)
+{
+    __shared__ __attribute__((aligned(16))) cd lds[kFft512Lds];
+    const int lane = threadIdx.x;
+    const long per_xcd = (gridDim.x + 7) >> 3;            // XCD-aware order: neighbouring frames share an XCD's L2
+    const long t0 = ((long)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3)) * run;
+    if (t0 >= n_frames) return;
+    const long t1 = t0 + run < n_frames ? t0 + run : n_frames;
+    double2 win[8];
+    {
+        const double2 *wp = reinterpret_cast<const double2 *>(table) + lane;
+#pragma unroll
+        for (int r = 0; r < 8; r++) win[r] = wp[64 * r];
+    }
+    cd b1 = w512<false>(tw, lane), b2 = w512<false>(tw, 8 * (lane & 7));
+    cd b3;
+    {
+        const double2 q = (reinterpret_cast<const double2 *>(table + 1024))[lane];
+        b3 = {q.x, q.y};
+    }
+    unsigned int raw[8];                                  // DW: the sample pair (2 lane + 128 r, + 1) of the current frame
+    short raw16[16];
+    auto fetch = [&](long t) {
+        const short *src = pcm + t * hop + 2 * lane;
+        if (DW) {
+#pragma unroll
+            for (int r = 0; r < 8; r++) raw[r] = *reinterpret_cast<const unsigned int *>(src + 128 * r);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 8; r++) { raw16[2 * r] = src[128 * r]; raw16[2 * r + 1] = src[128 * r + 1]; }
+        }
+    };
+    fetch(t0);
+#pragma unroll 1
+    for (long t = t0; t < t1; t++) {
+        cd v[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const int s0 = DW ? (int)(short)(raw[r] & 0xffffu) : (int)raw16[2 * r];
+            const int s1 = DW ? ((int)raw[r] >> 16) : (int)raw16[2 * r + 1];
+            v[r] = {(double)s0 * win[r].x, (double)s1 * win[r].y};
+        }
+        if (t + 1 < t1) fetch(t + 1);                     // in flight across this frame's arithmetic and stores
+        cd_opaque(b1); cd_opaque(b2); cd_opaque(b3);
+        cd_dft8<false>(v);
+        {
+            cd p[8];
+            cd_powers(b1, p);
+#pragma unroll
+            for (int k = 1; k < 8; k++) v[k] = cd_mul(v[k], p[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) lds[k * 72 + lane] = v[k];
+        lds_fence_wave();
+        {
+            const int base = (lane >> 3) * 72 + (lane & 7);
+#pragma unroll
+            for (int a = 0; a < 8; a++) v[a] = lds[base + 8 * a];
+        }
+        lds_fence_wave();
+        cd_dft8<false>(v);
+        {
+            cd p[8];
+            cd_powers(b2, p);
+#pragma unroll
+            for (int c = 1; c < 8; c++) v[c] = cd_mul(v[c], p[c]);
+        }
+        {
+            const int base = (lane >> 3) * 73 + (lane & 7);
+#pragma unroll
+            for (int c = 0; c < 8; c++) lds[base + 8 * c] = v[c];
+        }
+        lds_fence_wave();
+        {
+            const int base = (lane & 7) * 73 + (lane >> 3) * 8;
+#pragma unroll
+            for (int b = 0; b < 8; b++) v[b] = lds[base + b];
+        }
+        lds_fence_wave();
+        cd_dft8<false>(v);                                // v[d] = Z[lane + 64 d]
+        // natural-order image (slot 512 = Z[0]) for the mirrored operands.  (Tried: the split for m < 256 only, every item
+        // storing X[m], X[m + 512] AND their conjugates at 1024 - m and 512 - m -- half the split arithmetic, half this
+        // image's LDS traffic.  236-242 us against 204: a wave-store whose addresses DESCEND with the lane number is
+        // far slower than the ascending one, and un-reversing the lanes costs more than the image.
+        // profiles/r03_stft_f64.txt.)
+#pragma unroll
+        for (int d = 0; d < 8; d++) lds[lane + 64 * d] = v[d];
+        if (lane == 0) lds[512] = v[0];
+        lds_fence_wave();
+        typedef double f64x2 __attribute__((ext_vector_type(2)));
+        f64x2 *dst = reinterpret_cast<f64x2 *>(out + t * 1024 + lane);
+        // W16^d = exp(-2 pi j d / 16)
+        constexpr double c1 = 0.92387953251128675613, s1 = 0.38268343236508977173, h = 0.70710678118654752440;
+        const cd w16[8] = {{1.0, 0.0}, {c1, -s1}, {h, -h}, {s1, -c1}, {0.0, -1.0}, {-s1, -c1}, {-h, -h}, {-c1, -s1}};
+#pragma unroll
+        for (int d = 0; d < 8; d++) {
+            const cd zm = lds[512 - lane - 64 * d];
+            const cd w = d == 0 ? b3 : (d == 4 ? cd{b3.y, -b3.x} : cd_mul(b3, w16[d]));
+            const cd e = {v[d].x + zm.x, v[d].y - zm.y};                  // Z + conj Zm
+            const cd o = {v[d].y + zm.y, zm.x - v[d].x};                  // -j (Z - conj Zm)
+            const cd pp = cd_mul(o, w);
+            f64x2 lo = {0.5 * (e.x + pp.x), 0.5 * (e.y + pp.y)}, hi = {0.5 * (e.x - pp.x), 0.5 * (e.y - pp.y)};
+            __builtin_nontemporal_store(lo, dst + 64 * d);
+            __builtin_nontemporal_store(hi, dst + 64 * d + 512);
+        }
+        lds_fence_wave();                                 // the image is rewritten by the next frame's exchanges
+    }
+}
+
+// variant 0: stft1024_f64_v2_kernel (default), 1: round 2's stft1024_f64_kernel.  fpw: frames one wave walks (0 = default)
+int launch_stft1024_f64(hipStream_t stream, int n_cu, const short *pcm, long n_frames, long hop, const double *table,
+                        const double2 *tw512, double2 *out, int variant, int fpw)
 {
     if (n_frames <= 0) return 0;
-    const long slots = 4096;                                    // four waves per SIMD of a 256-CU part
-    const long run = (n_frames + slots - 1) / slots;
+    // variant 0: one frame per wave unless told otherwise -- short-lived waves behind the read pass, as in the FP32 path
+    // (204 us per 65,536 cold frames against 220 for one round of resident waves: profiles/r03_stft_f64.txt)
+    const long slots = 4096;
+    const long run = fpw > 0 ? fpw : (variant == 1 ? (n_frames + slots - 1) / slots : 1);
+    (void)n_cu;
     const long waves = (n_frames + run - 1) / run;
     const long grid = (waves + 7) / 8 * 8;
-    hipLaunchKernelGGL(stft1024_f64_kernel, dim3((unsigned)grid), dim3(64), 0, stream, pcm, n_frames, hop, table, tw512, out,
-                       (int)run);
+    if (variant == 1)
+        hipLaunchKernelGGL(stft1024_f64_kernel, dim3((unsigned)grid), dim3(64), 0, stream, pcm, n_frames, hop, table, tw512,
+                           out, (int)run);
+    else if ((((uintptr_t)pcm) & 3u) == 0 && (hop & 1) == 0)
+        hipLaunchKernelGGL(stft1024_f64_v2_kernel<true>, dim3((unsigned)grid), dim3(64), 0, stream, pcm, n_frames, hop, table,
+                           tw512, out, (int)run);
+    else
+        hipLaunchKernelGGL(stft1024_f64_v2_kernel<false>, dim3((unsigned)grid), dim3(64), 0, stream, pcm, n_frames, hop, table,
+                           tw512, out, (int)run);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

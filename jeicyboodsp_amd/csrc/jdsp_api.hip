@@ -193,6 +193,16 @@ int jdsp_set_option(jdsp_ctx *ctx, const char *name, long value)
         ctx->opt_stft_touch_wg = (int)value;
         return JDSP_OK;
     }
+    if (!strcmp(name, "stft.f64_kernel")) {
+        if (value != 0 && value != 1) return fail(ctx, JDSP_EINVAL, "stft.f64_kernel: 0 (four waves per SIMD) or 1 (round 2's kernel)");
+        ctx->opt_stft_f64_kernel = (int)value;
+        return JDSP_OK;
+    }
+    if (!strcmp(name, "stft.f64_frames_per_wave")) {
+        if (value < 0 || value > 4096) return fail(ctx, JDSP_EINVAL, "stft.f64_frames_per_wave out of range");
+        ctx->opt_stft_f64_fpw = (int)value;
+        return JDSP_OK;
+    }
     if (!strcmp(name, "stft.window")) {
         if (value != 0 && value != 1) return fail(ctx, JDSP_EINVAL, "stft.window: 0 (Hamming) or 1 (Hann)");
         ctx->opt_stft_window = (int)value;
@@ -586,8 +596,20 @@ int jdsp_stft_i16_f64_dev(jdsp_ctx *ctx, const int16_t *pcm_dev, long n_frames, 
         JDSP_HIP(ctx, hipMalloc((void **)&ctx->stft_f64_table, sizeof(double) * host.size()));
         JDSP_HIP(ctx, hipMemcpy(ctx->stft_f64_table, host.data(), sizeof(double) * host.size(), hipMemcpyHostToDevice));
     }
-    if (jdsp::launch_stft1024_f64(ctx->stream, pcm_dev, n_frames, hop, ctx->stft_f64_table, ctx->c2c_tw[9], (double2 *)spec_dev))
-        return fail(ctx, JDSP_EHIP, "stft f64 launch", hipGetLastError());
+    // hop-512 batches out of HBM: the read pass of the FP32 path (stft_kernels.hip), slab by slab -- the transform then
+    // finds its PCM in the Infinity Cache and the memory system sees a read stream, then a write stream
+    const int rp = ctx->opt_stft_read_pass;
+    const bool touch = hop == 512 && ((uintptr_t)pcm_dev & 15u) == 0 && (rp > 0 || (rp < 0 && n_frames >= 16384));
+    const long slab = touch ? 65536 : n_frames;
+    for (long f0 = 0; f0 < n_frames; f0 += slab) {
+        const long nf = n_frames - f0 < slab ? n_frames - f0 : slab;
+        if ((touch && jdsp::launch_pcm_read_pass(ctx->stream, ctx->n_cu, ctx->opt_stft_touch_wg, pcm_dev + f0 * hop, hop * (nf + 1))) ||
+            jdsp::launch_stft1024_f64(ctx->stream, ctx->n_cu, pcm_dev + f0 * hop, nf, hop, ctx->stft_f64_table, ctx->c2c_tw[9],
+                                      (double2 *)spec_dev + f0 * 1024, ctx->opt_stft_f64_kernel, ctx->opt_stft_f64_fpw)) {
+            const hipError_t le = hipGetLastError();
+            return fail(ctx, JDSP_EHIP, "stft f64 launch", le);
+        }
+    }
     return JDSP_OK;
 }
 

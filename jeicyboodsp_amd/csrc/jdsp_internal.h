@@ -26,6 +26,8 @@ struct jdsp_ctx {
     int opt_stft_read_pass = -1;       // read-only pass that pulls the PCM into the Infinity Cache before the transform:
                                        // 0 never, 1 always, -1 auto (large hop-512 batches); stft_kernels.hip
     int opt_stft_touch_wg = 0;         // tuning: workgroups per CU of that pass (0 = default)
+    int opt_stft_f64_kernel = 0;       // 0: stft1024_f64_v2_kernel, 1: round 2's stft1024_f64_kernel (A/B)
+    int opt_stft_f64_fpw = 0;          // frames one wave of the FP64 analysis walks (0 = one round of resident waves)
     float2 *stft1024_table_hann = nullptr, *win512_hann = nullptr;
     float2 *stft1024_table_rect = nullptr;   // rectangular window: the partitioned convolver's forward frames
     // device tables, created on first use
@@ -133,8 +135,9 @@ int launch_bitrev_table(hipStream_t stream, short *table_dev, int n_fft, int bit
 int launch_fft_process_f64(hipStream_t stream, const double2 *in, double2 *out, int n_fft, int log2n, long batch,
                            int forward, const double2 *tw);
 void fill_c2c_twiddles(double2 *t, int n_fft);
-int launch_stft1024_f64(hipStream_t stream, const short *pcm, long n_frames, long hop, const double *table,
-                        const double2 *tw512, double2 *out);
+int launch_stft1024_f64(hipStream_t stream, int n_cu, const short *pcm, long n_frames, long hop, const double *table,
+                        const double2 *tw512, double2 *out, int variant, int fpw);
+int launch_pcm_read_pass(hipStream_t stream, int n_cu, int wg_per_cu, const short *pcm, long n_samples);
 void fill_stft1024_f64_table(double *t);          // [1024 window doubles][512 double2 split twiddles]
 int launch_dft_direct_f64(hipStream_t stream, int kind, const void *in, double2 *inout, int n, long batch);
 

@@ -438,6 +438,12 @@ static int launch_pcm_touch(hipStream_t stream, int n_cu, int wg_per_cu, const s
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
+// the same pass for other transforms of hop-512 streams (the FP64 analysis, fft_c2c_kernels.hip)
+int launch_pcm_read_pass(hipStream_t stream, int n_cu, int wg_per_cu, const short *pcm, long n_samples)
+{
+    return launch_pcm_touch(stream, n_cu, wg_per_cu, pcm, n_samples);
+}
+
 // One slab of the fast path: frames [0, n_frames) of `pcm` with K frames per wave.
 static void launch_hop512_any(hipStream_t stream, int fpw_opt, const short *pcm, long n_frames, float2 *spec,
                               const float2 *table)

@@ -288,4 +288,69 @@ __device__ __forceinline__ void wave_fft512_x2(float2 (&a)[8], float2 (&b)[8], f
     dft8<INV>(b);
 }
 
+// ---- the passes of wave_fft512 as separate pieces, and two transforms STAGGERED by half a stage -------------------
+// wave_fft512_x2 issues both transforms' writes, then both transforms' reads, then waits: each fence covers two
+// transforms, but the wave still has nothing to issue while its reads are in flight.  Here transform b runs half a
+// stage behind a: a's exchange (8 writes, 8 reads) is in the LDS pipe while b's radix-8 pass and twiddles issue, and
+// the other way round -- one wave keeps the VALU and the LDS pipe busy together (LDS returns in order, so the wait
+// in front of a's next pass is a counted lgkmcnt that leaves b's exchange outstanding).  Separate scratch per
+// transform; the unswizzled second exchange (its address arithmetic is free).
+template <bool INV> __device__ __forceinline__ void fft512_pass1(float2 (&v)[8], const WaveTwiddles &tw)
+{
+    dft8<INV>(v);
+#pragma unroll
+    for (int k = 1; k < 8; k++) v[k] = INV ? cmul_conj(v[k], tw.t1[k - 1]) : cmul(v[k], tw.t1[k - 1]);
+}
+template <bool INV> __device__ __forceinline__ void fft512_pass2(float2 (&v)[8], const WaveTwiddles &tw)
+{
+    dft8<INV>(v);
+#pragma unroll
+    for (int c = 1; c < 8; c++) v[c] = INV ? cmul_conj(v[c], tw.t2[c - 1]) : cmul(v[c], tw.t2[c - 1]);
+}
+__device__ __forceinline__ void fft512_xchg1(float2 (&v)[8], float2 *lds, int lane)
+{
+#pragma unroll
+    for (int k = 0; k < 8; k++) lds[k * 72 + lane] = v[k];
+    wave_lds_fence();
+    const int base = (lane >> 3) * 72 + (lane & 7);
+#pragma unroll
+    for (int a = 0; a < 8; a++) v[a] = lds[base + 8 * a];
+}
+__device__ __forceinline__ void fft512_xchg2(float2 (&v)[8], float2 *lds, int lane)
+{
+    const int wb = (lane >> 3) * 73 + (lane & 7);
+#pragma unroll
+    for (int c = 0; c < 8; c++) lds[wb + 8 * c] = v[c];
+    wave_lds_fence();
+    const int rb = (lane & 7) * 73 + (lane >> 3) * 8;
+#pragma unroll
+    for (int b = 0; b < 8; b++) v[b] = lds[rb + b];
+}
+
+template <bool INV>
+__device__ __forceinline__ void wave_fft512_x2_staggered(float2 (&a)[8], float2 (&b)[8], float2 *lds_a, float2 *lds_b,
+                                                         int lane, const WaveTwiddles &tw)
+{
+    // sched_barrier: left to itself the scheduler sinks each exchange's reads down to the next exchange's writes (shorter
+    // live ranges) and the wave then waits for them with nothing left to issue
+    fft512_pass1<INV>(a, tw);
+    fft512_xchg1(a, lds_a, lane);
+    __builtin_amdgcn_sched_barrier(0);
+    fft512_pass1<INV>(b, tw);                 // under a's exchange
+    fft512_xchg1(b, lds_b, lane);
+    __builtin_amdgcn_sched_barrier(0);
+    fft512_pass2<INV>(a, tw);                 // under b's exchange
+    wave_lds_fence();
+    fft512_xchg2(a, lds_a, lane);
+    __builtin_amdgcn_sched_barrier(0);
+    fft512_pass2<INV>(b, tw);
+    wave_lds_fence();
+    fft512_xchg2(b, lds_b, lane);
+    __builtin_amdgcn_sched_barrier(0);
+    dft8<INV>(a);
+    __builtin_amdgcn_sched_barrier(0);
+    dft8<INV>(b);
+    wave_lds_fence();
+}
+
 }  // namespace jdsp

@@ -447,14 +447,17 @@ class Mfcc:
         self.eng._ck(L.jdsp_mfcc_liftering(self._h, _vp(cep), cep.shape[0]))
         return cep
 
-    def frames(self, pcm, n_frames=None, frame_start=None):
-        """Feature vectors [n_frames, n_cep] float64; frame j starts at frame_start[j] (default hop*j)."""
+    def frames(self, pcm, n_frames=None, frame_start=None, out=None):
+        """Feature vectors [n_frames, n_cep] float64; frame j starts at frame_start[j] (default hop*j).
+        out (device path only): a caller-owned [n_frames, n_cep] float64 CUDA tensor (no allocation: graph capture)."""
         if _is_torch(pcm):
             import torch
             assert pcm.is_cuda and pcm.dtype == torch.int16 and pcm.is_contiguous()
             if n_frames is None:
                 n_frames = len(frame_start) if frame_start is not None else self.n_frames(pcm.numel())
-            out = torch.empty((n_frames, self.cfg.n_cep), dtype=torch.float64, device=pcm.device)
+            if out is None:
+                out = torch.empty((n_frames, self.cfg.n_cep), dtype=torch.float64, device=pcm.device)
+            assert out.is_cuda and out.dtype == torch.float64 and out.is_contiguous() and out.numel() >= n_frames * self.cfg.n_cep
             if frame_start is not None:
                 assert frame_start.is_cuda and frame_start.dtype == torch.int64 and frame_start.numel() >= n_frames
             self.eng._use_torch_stream()

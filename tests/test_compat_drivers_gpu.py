@@ -433,7 +433,7 @@ def test_compat_denoise_per_block_calls_with_iframecount_256(tmp_path, oracle, w
     alt = np.where(np.arange(256) % 2 == 0, 1.0, -1.0)
     x = rng.normal(0, 3000, n_blocks * 256)
     for b0, n in ((0, 14), (40, 13)):                                     # sign-alternating quiet stretches: ZCR >= 200
-        x[b0 * 256:(b0 + n) * 256] = (np.abs(rng.normal(0, 45, (n, 256))) + 14.0).ravel() * np.tile(alt, n)
+        x[b0 * 256:(b0 + n) * 256] = (np.abs(rng.normal(0, 30, (n, 256))) + 14.0).ravel() * np.tile(alt, n)   # E ~ 350 < 700
     pcm = np.clip(np.rint(x), -32768, 32767).astype(np.int16)
     pcm.tofile(tmp_path / "in.raw")
     run("compat_selftest", what, tmp_path / "in.raw", tmp_path / "out.bin", 256)

@@ -194,15 +194,11 @@ def test_stft_read_pass_slabs_do_not_change_a_single_bit(eng, oracle):
         want = oracle.stft(pcm[512 * f0:512 * (f0 + 513)], 512)
         got = outs[1][f0:f0 + 512].cpu().numpy().astype(np.complex128)
         assert (np.abs(got - want) / np.abs(want).max(axis=1, keepdims=True)).max() < TOL
-    # 2 = the pass alone (tools/prefetch_probe.py): nothing is written
-    eng.set_option("stft.read_pass", 2)
-    keep = outs[2].clone()
-    eng.stft(d, n, out=outs[2])
-    torch.cuda.synchronize()
-    eng.set_option("stft.read_pass", -1)
-    assert torch.equal(torch.view_as_real(keep), torch.view_as_real(outs[2]))
-    with pytest.raises(Exception):
-        eng.set_option("stft.read_pass", 3)
+    # the option takes -1 / 0 / 1 only: the "pass alone" probe mode lives in a timing-only build (tools/prefetch_probe.py),
+    # the shipped library never returns without having written the spectra
+    for bad in (2, 3, -2):
+        with pytest.raises(Exception):
+            eng.set_option("stft.read_pass", bad)
 
 
 def test_full_batch_fp64_stft_agrees_with_the_headline_kernel(eng):

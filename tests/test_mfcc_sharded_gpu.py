@@ -8,9 +8,10 @@ vectors must be the single-GPU batch.  There is no halo and no collective: an ut
 How equal: the 512-FFT kernel puts frames 2j and 2j+1 OF THE CALL's frame list into one complex transform
 (mfcc512_pair_kernel), so a frame's partner -- and with it the FP32 rounding that leaks between the two spectra,
 6e-8 of the partner's magnitudes -- depends on the parity of the frame's position in the call.  A rank whose first
-frame has an even global index reproduces the batch bit for bit; one that starts on an odd index pairs every frame
-with its other neighbour and agrees to <= 2e-6 of each vector's peak (the same bound test_mfcc_gpu.py holds an
-utterance computed alone to).  Both are asserted, and every rank is held to the oracle on a sample of utterances.
+frame has an even global index reproduces the batch bit for bit (up to its last frame, if it holds an odd number of
+them: that one is alone in its transform); one that starts on an odd index pairs every frame with its other neighbour
+and agrees to <= 2e-5 of each vector's peak (two FP32 results, each within north_star's 1e-5 of the FP64 oracle).
+Both are asserted, and every rank is held to the oracle on a sample of utterances.
 """
 import numpy as np
 import pytest
@@ -68,12 +69,17 @@ def test_utterance_sharded_mfcc_equals_the_single_gpu_batch(eng, oracle, batch, 
         torch.cuda.synchronize()
         want = whole[f0:f1]
         assert got.shape == want.shape
-        if f0 % 2 == 0:                                                     # same pairing as the batch: bit for bit
-            assert torch.equal(got.view(torch.int64), want.view(torch.int64))
+        err = ((got - want).abs() / want.abs().amax(dim=1, keepdim=True)).max().item()
+        # whatever the pairing: both results are FP32 chains held to 1e-5 of the FP64 oracle, so 2e-5 of each other.  (Over
+        # 3.5 M noise frames the largest difference seen is 9.7e-6: a frame whose low channels happen to be 40 dB below
+        # its own average takes the transform's rounding floor relative to those channels, ln() divides by them.)
+        assert err < 2e-5, err
+        if f0 % 2 == 0:
+            # same pairs as the batch -> bit for bit; except the shard's LAST frame when its length is odd: alone in
+            # its transform here, paired with the next rank's first frame in the batch
+            n_same = (f1 - f0) & ~1
+            assert torch.equal(got[:n_same].view(torch.int64), want[:n_same].view(torch.int64))
             exact_ranks += 1
-        else:                                                               # every frame has its OTHER neighbour as partner
-            err = ((got - want).abs() / want.abs().amax(dim=1, keepdim=True)).max().item()
-            assert err < 2e-6, err
         # and against the oracle, first and last utterance of the shard
         for u in (u0, u0 + nu - 1):
             a, b = int(np.sum(nf[u0:u])), int(np.sum(nf[u0:u + 1]))

@@ -180,17 +180,20 @@ def test_gpu_melfilterbank_dct_liftering_match_the_reference(eng, tail):
 
 @pytest.mark.gpu
 def test_gpu_production_mfcc_tail_within_1e5_of_the_reference_tail(eng, tail, oracle):
-    """jdsp_mfcc_frames (FP32 transform, FP32 filterbank, FP64 DCT) against the REFERENCE's tail fed with the
-    oracle's FP64 |X| of the same frames: whatever the kernel's own tail does differently shows here."""
+    """jdsp_mfcc_frames (FP32 transform, FP32 filterbank, FP64 DCT) against the REFERENCE's tail fed with an FP64 |X|
+    of the same frames (numpy's DFT where the reference calls FFTW): whatever the kernel's own tail does differently
+    shows here."""
     import oracle_lib
     rng = np.random.default_rng(5)
     pcm = np.clip(np.rint(rng.normal(0, 2500, 1024 * 6)), -32768, 32767).astype(np.int16)
     m = eng.mfcc()
     got = m.frames(pcm)                                   # hop 512: 11 frames
     cfg = oracle.mfcc_native_cfg()
-    w = 0.54 - 0.46 * np.cos(2 * 3.141592 * np.arange(1024) / 1023)
-    frames = np.stack([pcm[512 * j:512 * j + 1024] * w for j in range(got.shape[0])])
-    mag = np.abs(np.fft.fft(frames, axis=1))[:, :512]
+    raw = np.stack([pcm[512 * j:512 * j + 1024].astype(np.float64) for j in range(got.shape[0])])
+    frames = np.zeros_like(raw)
+    frames[:, 1:] = raw[:, 1:] - 0.96 * raw[:, :-1]       # pre-emphasis, sample 0 left at 0 (MFCC:207-209)
+    frames *= oracle.hamming(1024)                        # MFCC:211-213
+    mag = np.abs(np.fft.fft(frames, axis=1))[:, :512]     # MFCC:215-219 (FFTW's contract: the unnormalised DFT)
     ref = oracle_lib.load_ref_mfcc_tail()
     if ref is not None:                                   # authoring container: straight through the compiled reference
         want = ref.liftering(ref.dct(ref.mel_filterbank(mag)))
