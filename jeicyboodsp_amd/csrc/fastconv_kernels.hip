@@ -15,6 +15,16 @@
 
 namespace jdsp {
 
+// Diagnostic build only (-DJDSP_STAMP, tools/wave_timeline.py): every wave of fastconv1024_pairs_kernel records when it
+// started and ended (s_memrealtime: the 100 MHz constant clock) and where it ran (HW_ID: SIMD, CU, SE, XCC_ID).  The
+// values go to a buffer nothing else reads; no output is computed from them.
+#ifndef JDSP_STAMP
+#define JDSP_STAMP 0
+#endif
+#if JDSP_STAMP
+__device__ unsigned long long g_wave_stamp[3 * 8192];
+#endif
+
 __device__ __forceinline__ float conv_sample(const ConvStream &s, long pos)
 {
     if (pos + s.global0 < s.valid_from) return 0.f;
@@ -204,6 +214,9 @@ __global__ __launch_bounds__(64, JDSP_CONV1024_MINWAVES) void fastconv1024_pairs
     __shared__ __attribute__((aligned(16))) float2 lds[(NF == 2 && JDSP_CONV1024_X2) ? 2 * kWaveLdsComplex : kWaveLdsComplex];
     const int lane = threadIdx.x;
     if ((long)blockIdx.x >= n_out_blocks) return;
+#if JDSP_STAMP
+    const unsigned long long stamp_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
     if (blockIdx.x == gridDim.x - 1 && hist_out) {
         // the history the next call starts from (conv_hist_update_kernel's job, without its launch): the last
         // hist_len samples of [previous history | this call's samples]; hist_out is the other of the handle's two buffers
@@ -353,7 +366,25 @@ __global__ __launch_bounds__(64, JDSP_CONV1024_MINWAVES) void fastconv1024_pairs
             }
         }
     }
+#if JDSP_STAMP
+    if (lane == 0 && blockIdx.x < 8192) {
+        unsigned int hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        unsigned int xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        g_wave_stamp[3 * blockIdx.x] = stamp_t0;
+        g_wave_stamp[3 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+        g_wave_stamp[3 * blockIdx.x + 2] = ((unsigned long long)xcc << 32) | hw;
+    }
+#endif
 }
+
+#if JDSP_STAMP
+int read_wave_stamps(unsigned long long *host, int n)
+{
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_wave_stamp), sizeof(unsigned long long) * 3 * (size_t)n) == hipSuccess ? 0 : -1;
+}
+#endif
 
 // ---------------------------------------------------------------------------------------
 // n_fft = 8192.  512 threads; thread t (wave w = t >> 6, lane l = t & 63).

@@ -332,6 +332,9 @@ __device__ __forceinline__ void cd_powers(const cd &b, cd (&p)[8])
     p[7] = cd_mul(p[4], p[3]);
 }
 
+#ifndef JDSP_F64_PLAIN_STORES
+#define JDSP_F64_PLAIN_STORES 0
+#endif
 template <bool DW>
 __global__ __launch_bounds__(64, 4) void stft1024_f64_v2_kernel(const short *__restrict__ pcm, long n_frames, long hop,
                                                                const double *__restrict__ table,
@@ -438,8 +441,13 @@ __global__ __launch_bounds__(64, 4) void stft1024_f64_v2_kernel(const short *__r
             const cd o = {v[d].y + zm.y, zm.x - v[d].x};                  // -j (Z - conj Zm)
             const cd pp = cd_mul(o, w);
             f64x2 lo = {0.5 * (e.x + pp.x), 0.5 * (e.y + pp.y)}, hi = {0.5 * (e.x - pp.x), 0.5 * (e.y - pp.y)};
+#if JDSP_F64_PLAIN_STORES                                 /* timing-only A/B: cached stores instead of nontemporal ones */
+            dst[64 * d] = lo;
+            dst[64 * d + 512] = hi;
+#else
             __builtin_nontemporal_store(lo, dst + 64 * d);
             __builtin_nontemporal_store(hi, dst + 64 * d + 512);
+#endif
         }
         lds_fence_wave();                                 // the image is rewritten by the next frame's exchanges
     }

@@ -237,11 +237,11 @@ int launch_mvdr_shard_finish(hipStream_t s, const short *left_ext, const short *
 int launch_mvdrn(hipStream_t s, const short *pcm, long chan_stride, int n_mics, long n_blocks, long calls_before,
                  const short *prev_in, short *prev_out, const int *events, const DenoisePlan *plan, const int *ver_base,
                  const unsigned long long *snap_mask, float2 *spec, const double2 *cov_in, double2 *cov_out,
-                 const double2 *steer, double loading, float2 *weights, const float2 *table, short *out, float *precast, double2 *chunk_ws);
+                 const double2 *steer, double loading, float2 *weights, const float2 *table, short *out, float *precast, double2 *chunk_ws, int chunk_cap);
 int launch_mvdrn512(hipStream_t s, const short *pcm, long chan_stride, int n_mics, long n_blocks, long calls_before,
                     const short *prev_in, short *prev_out, const int *events, const DenoisePlan *plan, const int *ver_base,
                     const unsigned long long *snap_mask, float2 *spec, const double2 *cov_in, double2 *cov_out,
-                    const double2 *steer, double loading, float2 *weights, const float2 *table, short *out, float *precast, double2 *chunk_ws);
+                    const double2 *steer, double loading, float2 *weights, const float2 *table, short *out, float *precast, double2 *chunk_ws, int chunk_cap);
 // pitch_kernels.hip
 int launch_pitch(hipStream_t s, const short *pcm, long n_blocks, const short *prev_block, const float2 *table, int *arg,
                  float *rmax, float *autocorr);
@@ -382,5 +382,6 @@ struct jdsp_mvdrn {
     int *events = nullptr, *ev_n = nullptr, *ver_base = nullptr;
     unsigned long long *snap_mask = nullptr;
     float2 *spec = nullptr, *weights = nullptr;
-    double2 *chunk_ws = nullptr;              // [2][kMvnChunks][n_bins][64]: per-chunk covariance sums and entering matrices
+    double2 *chunk_ws = nullptr;              // [2][chunk_cap][n_bins][64]: per-chunk covariance sums and entering matrices (sized with the workspace)
+    int chunk_cap = 0;
 };

@@ -5,13 +5,15 @@ using jdsp::fail;
 
 static void mvdrn_free_ws(jdsp_mvdrn *h)
 {
-    void *p[] = {h->flags, h->events, h->ev_n, h->ver_base, h->snap_mask, h->spec, h->weights};
+    void *p[] = {h->flags, h->events, h->ev_n, h->ver_base, h->snap_mask, h->spec, h->weights, h->chunk_ws};
     for (void *q : p)
         if (q) (void)hipFree(q);
     h->flags = nullptr;
     h->events = h->ev_n = h->ver_base = nullptr;
     h->snap_mask = nullptr;
     h->spec = h->weights = nullptr;
+    h->chunk_ws = nullptr;
+    h->chunk_cap = 0;
     h->cap_blocks = 0;
 }
 
@@ -58,7 +60,6 @@ int jdsp_mvdrn_create_cfg(jdsp_ctx *ctx, int n_mics, const double *delays_s, dou
         if (e == hipSuccess) e = hipMalloc((void **)&h->run_len[i], sizeof(int));
     }
     if (e == hipSuccess) e = hipMalloc((void **)&h->plan, sizeof(jdsp::DenoisePlan));
-    if (e == hipSuccess) e = hipMalloc((void **)&h->chunk_ws, sizeof(double2) * 2 * jdsp::kMvnChunks * (size_t)513 * 64);
     if (e == hipSuccess) e = hipMalloc((void **)&h->steer, sizeof(double2) * steer.size());
     if (e == hipSuccess) e = hipMalloc((void **)&h->w_vad, sizeof(w));
     if (e == hipSuccess) e = hipMemcpy(h->steer, steer.data(), sizeof(double2) * steer.size(), hipMemcpyHostToDevice);
@@ -88,7 +89,6 @@ int jdsp_mvdrn_destroy(jdsp_mvdrn *h)
         if (h->run_len[i]) (void)hipFree(h->run_len[i]);
     }
     if (h->plan) (void)hipFree(h->plan);
-    if (h->chunk_ws) (void)hipFree(h->chunk_ws);
     if (h->steer) (void)hipFree(h->steer);
     if (h->w_vad) (void)hipFree(h->w_vad);
     delete h;
@@ -131,11 +131,16 @@ static int mvdrn_reserve(jdsp_mvdrn *h, long n_blocks)
     // worst case: every block is an estimation frame -- one spectrum set and one weight set per block
     if (e == hipSuccess) e = hipMalloc((void **)&h->spec, n * h->n_mics * (size_t)h->n_bins * sizeof(float2));
     if (e == hipSuccess) e = hipMalloc((void **)&h->weights, (n + 1) * (size_t)h->n_bins * 8 * sizeof(float2));
+    // the chunked covariance update's sums and entering matrices: a call of n blocks has at most min(n, kMvnChunks) chunks
+    // (1 KB per bin and chunk: 134 MB at 128 chunks of 513 bins -- a per-block caller gets 1 MB)
+    const int chunk_cap = (int)(n < (size_t)jdsp::kMvnChunks ? n : (size_t)jdsp::kMvnChunks);
+    if (e == hipSuccess) e = hipMalloc((void **)&h->chunk_ws, sizeof(double2) * 2 * (size_t)chunk_cap * (size_t)h->n_bins * 64);
     if (e != hipSuccess) {
         mvdrn_free_ws(h);
         return fail(ctx, JDSP_ENOMEM, "jdsp_mvdrn: workspace", e);
     }
     h->cap_blocks = n_blocks;
+    h->chunk_cap = chunk_cap;
     return JDSP_OK;
 }
 
@@ -162,7 +167,7 @@ int jdsp_mvdrn_process_dev(jdsp_mvdrn *h, const int16_t *pcm_dev, long chan_stri
                                   h->events, h->ev_n, h->plan) ||
             jdsp::launch_mvdrn512(s, pcm_dev, chan_stride, h->n_mics, n_blocks, h->calls, h->prev[in], h->prev[ou], h->events,
                                   h->plan, h->ver_base, h->snap_mask, h->spec, h->cov[in], h->cov[ou], h->steer, h->loading,
-                                  h->weights, ctx->stft1024_table, out_dev, precast_dev, h->chunk_ws))
+                                  h->weights, ctx->stft1024_table, out_dev, precast_dev, h->chunk_ws, h->chunk_cap))
             return fail(ctx, JDSP_EHIP, "mvdrn512 launch", hipGetLastError());
         h->cur ^= 1;
         h->calls += n_blocks;
@@ -173,7 +178,7 @@ int jdsp_mvdrn_process_dev(jdsp_mvdrn *h, const int16_t *pcm_dev, long chan_stri
                               h->ev_n, h->plan) ||
         jdsp::launch_mvdrn(s, pcm_dev, chan_stride, h->n_mics, n_blocks, h->calls, h->prev[in], h->prev[ou], h->events,
                            h->plan, h->ver_base, h->snap_mask, h->spec, h->cov[in], h->cov[ou], h->steer, h->loading,
-                           h->weights, ctx->stft1024_table, out_dev, precast_dev, h->chunk_ws))
+                           h->weights, ctx->stft1024_table, out_dev, precast_dev, h->chunk_ws, h->chunk_cap))
         return fail(ctx, JDSP_EHIP, "mvdrn launch", hipGetLastError());
     h->cur ^= 1;
     h->calls += n_blocks;

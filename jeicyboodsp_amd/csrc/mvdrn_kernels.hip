@@ -452,12 +452,13 @@ __global__ __launch_bounds__(64) void mvdrn_apply_pairs_kernel(const short *__re
     }
 }
 
-// chunk_ws: 2 * kMvnChunks * n_bins * 64 double2 (the chunk sums, then the matrices entering the chunks)
+// chunk_ws: 2 * chunk_cap * n_bins * 64 double2 (the chunk sums, then the matrices entering the chunks), [chunk][bin][64];
+// chunk_cap = min(blocks the workspace is sized for, kMvnChunks) >= the chunks any call of that size can have
 static void launch_mvdrn_update(hipStream_t s, const float2 *spec, int n_mics, int n_bins, double inv_n, const DenoisePlan *plan,
-                                const double2 *cov_in, double2 *cov_out, double2 *chunk_ws, const double2 *steer, double loading,
-                                float2 *weights)
+                                const double2 *cov_in, double2 *cov_out, double2 *chunk_ws, int chunk_cap, const double2 *steer,
+                                double loading, float2 *weights)
 {
-    double2 *sums = chunk_ws, *start = chunk_ws + (size_t)kMvnChunks * n_bins * 64;
+    double2 *sums = chunk_ws, *start = chunk_ws + (size_t)chunk_cap * n_bins * 64;
     hipLaunchKernelGGL(mvdrn_chunk_sums_kernel, dim3((n_bins + 7) / 8, kMvnChunks), dim3(64), 0, s, spec, n_mics, n_bins, inv_n, plan, sums);
     hipLaunchKernelGGL(mvdrn_chunk_prefix_kernel, dim3(n_bins), dim3(64), 0, s, sums, n_mics, n_bins, plan, cov_in, cov_out, start);
     hipLaunchKernelGGL(mvdrn_update_kernel, dim3((n_bins + 7) / 8, kMvnChunks), dim3(64), 0, s, spec, n_mics, n_bins, inv_n, plan, start,
@@ -468,13 +469,13 @@ int launch_mvdrn(hipStream_t s, const short *pcm, long chan_stride, int n_mics, 
                  const short *prev_in, short *prev_out, const int *events, const DenoisePlan *plan, const int *ver_base,
                  const unsigned long long *snap_mask, float2 *spec, const double2 *cov_in, double2 *cov_out,
                  const double2 *steer, double loading, float2 *weights, const float2 *table, short *out, float *precast,
-                 double2 *chunk_ws)
+                 double2 *chunk_ws, int chunk_cap)
 {
     if (n_blocks <= 0) return 0;
     const long g1 = n_blocks * n_mics < 4096 ? n_blocks * n_mics : 4096;
     hipLaunchKernelGGL(mvdrn_event_spectra_kernel, dim3((unsigned)g1), dim3(64), 0, s, pcm, chan_stride, n_mics, n_blocks,
                        prev_in, events, plan, table, spec);
-    launch_mvdrn_update(s, spec, n_mics, kMvnBins, 1.0 / 1024.0, plan, cov_in, cov_out, chunk_ws, steer, loading, weights);
+    launch_mvdrn_update(s, spec, n_mics, kMvnBins, 1.0 / 1024.0, plan, cov_in, cov_out, chunk_ws, chunk_cap, steer, loading, weights);
     const long grid = (n_blocks + 7) / 8 * 8;
 #if JDSP_MVN_APPLY_PAIRS
     hipLaunchKernelGGL(mvdrn_apply_pairs_kernel, dim3((unsigned)grid), dim3(64), 0, s, pcm, chan_stride, n_mics, n_blocks,
@@ -704,14 +705,14 @@ int launch_mvdrn512(hipStream_t s, const short *pcm, long chan_stride, int n_mic
                     const short *prev_in, short *prev_out, const int *events, const DenoisePlan *plan, const int *ver_base,
                     const unsigned long long *snap_mask, float2 *spec, const double2 *cov_in, double2 *cov_out,
                     const double2 *steer, double loading, float2 *weights, const float2 *table, short *out, float *precast,
-                    double2 *chunk_ws)
+                    double2 *chunk_ws, int chunk_cap)
 {
     if (n_blocks <= 0) return 0;
     const long work = n_blocks * ((n_mics + 1) / 2);
     const long g1 = work < 4096 ? work : 4096;
     hipLaunchKernelGGL(mvdrn512_event_spectra_kernel, dim3((unsigned)g1), dim3(64), 0, s, pcm, chan_stride, n_mics, n_blocks,
                        prev_in, events, plan, table, spec);
-    launch_mvdrn_update(s, spec, n_mics, kMvn512Bins, 1.0 / 512.0, plan, cov_in, cov_out, chunk_ws, steer, loading, weights);
+    launch_mvdrn_update(s, spec, n_mics, kMvn512Bins, 1.0 / 512.0, plan, cov_in, cov_out, chunk_ws, chunk_cap, steer, loading, weights);
     const long grid = ((n_blocks + 1) / 2 + 7) / 8 * 8;
     hipLaunchKernelGGL(mvdrn512_apply_kernel, dim3((unsigned)grid), dim3(64), 0, s, pcm, chan_stride, n_mics, n_blocks,
                        calls_before, prev_in, prev_out, ver_base, snap_mask, weights, table, out, precast);

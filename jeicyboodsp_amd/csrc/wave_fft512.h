@@ -11,7 +11,7 @@
 //   pass 1  lane l        : A[k1]   = sum_r z[l+64r] w_8^(r k1);  A[k1] *= w_512^(l k1)
 //   xchg 1  write k1*72+l ; lane l'=8*k1+b reads k1*72+8a+b          (72: bank spread)
 //   pass 2  lane (k1,b)   : B[c]    = sum_a A[k1][8a+b] w_8^(a c);  B[c] *= w_64^(b c)
-//   xchg 2  write k1*73+8c+b ; lane l''=k1+8c reads k1*73+8c+b'      (73: bank spread)
+//   xchg 2  element (k1,c,b) at u(k1)+b+72c+(c&3), written by lane 8*k1+b, read by lane k1+8c (see xchg2_u below)
 //   pass 3  lane (k1,c)   : Z[k1+8c+64d] = sum_b B[k1][c][b] w_8^(b d)
 // so lane l ends up holding Z[l + 64 d] in v[d] -- the same "lane + 64*r"
 // layout the input came in.  The inverse transform conjugates every twiddle.
@@ -147,6 +147,29 @@ __device__ __forceinline__ void load_wave_twiddles(WaveTwiddles &tw, const float
     for (int c = 0; c < 7; c++) tw.t2[c] = table[kTwT2 + c * 8 + (lane & 7)];
 }
 
+// Second exchange, element (k1, c, b): written by lane 8 k1 + b from register c, read by lane k1 + 8 c into register b.
+// Round 1-2 kept it at k1 * 73 + 8 c + b: conflict-free for the reads (ds_read_b64: 64 banks over 32 lanes) but not for
+// the writes -- a ds_write_b64 is served 16 lanes at a time over 32 banks, and lanes (k1 odd, b = 7) and (k1 even,
+// b = 0) of a group met in one bank: one extra LDS cycle per group, 4 per write, 96 per block of the HRIR convolver
+// = all of its SQ_LDS_BANK_CONFLICT (16.7 % of its LDS cycles, profiles/r02_chains_sq_counters.txt).  The layout
+//     u(k1) + b + 72 c + (c & 3),   u = 8 (k1 & 1) + 36 ((k1 >> 1) & 1) + 16 (k1 >> 2)      (max 574 < kWaveLdsComplex)
+// is conflict-free on both sides under those two bank maps (MI355X_MICROARCH.md, LDS; found by exhaustive search over
+// separable maps) and stays separable: the writer's lane part is u(k1) + b with the c part as instruction offsets, the
+// reader's is u(k1) + 72 c + (c & 3) with b = 0..7 consecutive -- no per-register address arithmetic on either side.
+#ifndef JDSP_XCHG2_PITCH73
+#define JDSP_XCHG2_PITCH73 0        // 1: rounds 1-2's k1 * 73 + 8 c + b (A/B timing)
+#endif
+#if JDSP_XCHG2_PITCH73
+__device__ __forceinline__ int xchg2_wbase(int lane) { return (lane >> 3) * 73 + (lane & 7); }
+__device__ __forceinline__ int xchg2_rbase(int lane) { return (lane & 7) * 73 + (lane >> 3) * 8; }
+constexpr int xchg2_coff(int c) { return 8 * c; }
+#else
+__device__ __forceinline__ int xchg2_u(int k1) { return 8 * (k1 & 1) + 36 * ((k1 >> 1) & 1) + 16 * (k1 >> 2); }
+__device__ __forceinline__ int xchg2_wbase(int lane) { return xchg2_u(lane >> 3) + (lane & 7); }
+__device__ __forceinline__ int xchg2_rbase(int lane) { const int c = lane >> 3; return xchg2_u(lane & 7) + 72 * c + (c & 3); }
+constexpr int xchg2_coff(int c) { return 72 * c + (c & 3); }
+#endif
+
 // XOR-swizzled second exchange (conflict-free writes and reads).  Measured in steady state, A/B/A/B:
 // the two-transform form gains 3 % with it (MFCC 96 -> 93 us), the one-transform kernels are unchanged or 2-3 %
 // slower (its extra address arithmetic), so each form has its own switch.
@@ -154,7 +177,7 @@ __device__ __forceinline__ void load_wave_twiddles(WaveTwiddles &tw, const float
 #define JDSP_XCHG2_SWIZZLE 0
 #endif
 #ifndef JDSP_XCHG2_SWIZZLE_X2
-#define JDSP_XCHG2_SWIZZLE_X2 1
+#define JDSP_XCHG2_SWIZZLE_X2 0      // round 2 had 1 here (against the pitch-73 layout's write conflicts)
 #endif
 // Second exchange, swizzled form: element (k1, c, b) -- written by lane 8 k1 + b from register c, read by lane
 // k1 + 8 c into register b -- lives at 16 (4 c + (k1 >> 1)) + (((2 b) | (k1 & 1)) ^ 2 (k1 >> 1) ^ 8 (c & 1)).
@@ -205,13 +228,13 @@ __device__ __forceinline__ void wave_fft512(float2 (&v)[8], float2 *lds, int lan
     }
 #else
     {
-        const int base = (lane >> 3) * 73 + (lane & 7);
+        const int base = xchg2_wbase(lane);
 #pragma unroll
-        for (int c = 0; c < 8; c++) lds[base + 8 * c] = v[c];
+        for (int c = 0; c < 8; c++) lds[base + xchg2_coff(c)] = v[c];
     }
     wave_lds_fence();
     {
-        const int base = (lane & 7) * 73 + (lane >> 3) * 8;
+        const int base = xchg2_rbase(lane);
 #pragma unroll
         for (int b = 0; b < 8; b++) v[b] = lds[base + b];
     }
@@ -272,13 +295,13 @@ __device__ __forceinline__ void wave_fft512_x2(float2 (&a)[8], float2 (&b)[8], f
     }
 #else
     {
-        const int base = (lane >> 3) * 73 + (lane & 7);
+        const int base = xchg2_wbase(lane);
 #pragma unroll
-        for (int c = 0; c < 8; c++) { lds_a[base + 8 * c] = a[c]; lds_b[base + 8 * c] = b[c]; }
+        for (int c = 0; c < 8; c++) { lds_a[base + xchg2_coff(c)] = a[c]; lds_b[base + xchg2_coff(c)] = b[c]; }
     }
     wave_lds_fence();
     {
-        const int base = (lane & 7) * 73 + (lane >> 3) * 8;
+        const int base = xchg2_rbase(lane);
 #pragma unroll
         for (int q = 0; q < 8; q++) { a[q] = lds_a[base + q]; b[q] = lds_b[base + q]; }
     }
@@ -318,11 +341,11 @@ __device__ __forceinline__ void fft512_xchg1(float2 (&v)[8], float2 *lds, int la
 }
 __device__ __forceinline__ void fft512_xchg2(float2 (&v)[8], float2 *lds, int lane)
 {
-    const int wb = (lane >> 3) * 73 + (lane & 7);
+    const int wb = xchg2_wbase(lane);
 #pragma unroll
-    for (int c = 0; c < 8; c++) lds[wb + 8 * c] = v[c];
+    for (int c = 0; c < 8; c++) lds[wb + xchg2_coff(c)] = v[c];
     wave_lds_fence();
-    const int rb = (lane & 7) * 73 + (lane >> 3) * 8;
+    const int rb = xchg2_rbase(lane);
 #pragma unroll
     for (int b = 0; b < 8; b++) v[b] = lds[rb + b];
 }
