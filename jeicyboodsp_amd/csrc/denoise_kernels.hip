@@ -916,7 +916,7 @@ __global__ __launch_bounds__(64, JDSP_DENOISE_MINWAVES) void denoise_kernel(
             unsigned int *dst = reinterpret_cast<unsigned int *>(out + oi * 512) + lane;
 #pragma unroll
             for (int d = 0; d < 4; d++)                      // four coalesced 256-byte stores, in the layout as is
-                __builtin_nontemporal_store(cast_i16_bits(o[d].x) | (cast_i16_bits(o[d].y) << 16), dst + 64 * d);
+                __builtin_nontemporal_store(cast_i16x2_bits(o[d].x, o[d].y), dst + 64 * d);
             if (precast) {
 #pragma unroll
                 for (int d = 0; d < 4; d++) *reinterpret_cast<float2 *>(precast + oi * 512 + 2 * lane + 128 * d) = o[d];
@@ -940,6 +940,9 @@ __global__ __launch_bounds__(64, JDSP_DENOISE_MINWAVES) void denoise_kernel(
 // iteration that precedes their use (4 dwords per lane) instead of all K + 2 blocks up front (40 VGPRs at K = 8).
 #ifndef JDSP_DENOISE_RESIDENT
 #define JDSP_DENOISE_RESIDENT (JDSP_DENOISE_PAIRS ? 4 : 3)      // waves per SIMD the run kernel's register budget allows
+#endif
+#ifndef JDSP_DENOISE_PRIO
+#define JDSP_DENOISE_PRIO 1                                      // 1: the run kernels' waves rotate through the priority levels
 #endif
 template <int MODE>
 __global__ __launch_bounds__(64, JDSP_DENOISE_RESIDENT) void denoise_run_kernel(
@@ -997,7 +1000,18 @@ __global__ __launch_bounds__(64, JDSP_DENOISE_RESIDENT) void denoise_run_kernel(
         for (int d = 0; d < 4; d++) tail[d] = y[d + 4];
     }
     const long first_emit = sh.emit_from;                     // SS:260-263: calls 1 and 2 emit nothing
+    // every wave walks the priority levels, one step per block (see fastconv1024_pairs_kernel: a SIMD serves equal-priority
+    // waves by age, and equal shares then finish far apart)
+    unsigned prio_step = blockIdx.x >> 10;
     for (long j = j0; j < j1; j++) {
+#if JDSP_DENOISE_PRIO
+        switch (prio_step++ & 3u) {
+        case 0: __builtin_amdgcn_s_setprio(0); break;
+        case 1: __builtin_amdgcn_s_setprio(1); break;
+        case 2: __builtin_amdgcn_s_setprio(2); break;
+        default: __builtin_amdgcn_s_setprio(3); break;
+        }
+#endif
         unsigned int cur[4];
 #pragma unroll
         for (int r = 0; r < 4; r++) { cur[r] = nxt[r]; raw[r] = raw[r + 4]; raw[r + 4] = nxt[r]; }
@@ -1024,7 +1038,7 @@ __global__ __launch_bounds__(64, JDSP_DENOISE_RESIDENT) void denoise_run_kernel(
             unsigned int *dst = reinterpret_cast<unsigned int *>(out + oi * 512) + lane;
 #pragma unroll
             for (int d = 0; d < 4; d++)                      // four coalesced 256-byte stores, in the layout as is
-                __builtin_nontemporal_store(cast_i16_bits(o[d].x) | (cast_i16_bits(o[d].y) << 16), dst + 64 * d);
+                __builtin_nontemporal_store(cast_i16x2_bits(o[d].x, o[d].y), dst + 64 * d);
             if (precast) {
 #pragma unroll
                 for (int d = 0; d < 4; d++) *reinterpret_cast<float2 *>(precast + oi * 512 + 2 * lane + 128 * d) = o[d];
@@ -1572,7 +1586,16 @@ __global__ __launch_bounds__(64, JDSP_DENOISE512_WAVES(MODE)) void denoise512_ru
     const float *row_a = nullptr, *row_b = nullptr;
     const long first_emit = sh.emit_from;
     bool halo = true;                                         // frame j0 - 1 only rebuilds the overlap tail
+    unsigned prio_step = blockIdx.x >> 10;                    // as in denoise_run_kernel: one priority step per frame pair
     for (long ja = j0 - 1; ja < j1; ja += 2) {
+#if JDSP_DENOISE_PRIO
+        switch (prio_step++ & 3u) {
+        case 0: __builtin_amdgcn_s_setprio(0); break;
+        case 1: __builtin_amdgcn_s_setprio(1); break;
+        case 2: __builtin_amdgcn_s_setprio(2); break;
+        default: __builtin_amdgcn_s_setprio(3); break;
+        }
+#endif
         const long jb = ja + 1;
         if (ja + 2 < j1) {                                    // the next pair's two new blocks, needed one iteration from now
             if (ja + 2 >= 0 && ja + 4 <= n_blocks) {            // both inside this call's buffer (wave-uniform)

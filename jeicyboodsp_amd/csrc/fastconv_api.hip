@@ -6,6 +6,9 @@ using jdsp::fail;
 #ifndef JDSP_STAMP
 #define JDSP_STAMP 0
 #endif
+#if JDSP_STAMP
+namespace jdsp { int read_wave_stamps(unsigned long long *host, int n); }
+#endif
 extern "C" {
 
 int jdsp_fastconv_create(jdsp_ctx *ctx, const double *taps, int n_taps, int n_filters, int n_fft, jdsp_fastconv **out)
@@ -222,7 +225,6 @@ int jdsp_fastconv_process(jdsp_fastconv *h, const int16_t *pcm_host, long n_bloc
 }
 
 #if JDSP_STAMP
-namespace jdsp { int read_wave_stamps(unsigned long long *host, int n); }
 /* diagnostic build only (tools/wave_timeline.py): (start, end, where) of the last convolver launch's first n waves */
 int jdsp_debug_wave_stamps(unsigned long long *host, int n) { return jdsp::read_wave_stamps(host, n); }
 #endif

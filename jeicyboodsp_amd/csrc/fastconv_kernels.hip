@@ -138,7 +138,7 @@ __global__ __launch_bounds__(64) void fastconv1024_kernel(ConvStream s, long n_o
         unsigned int *o32 = reinterpret_cast<unsigned int *>(o + head);
         for (int p = lane; p < n_pairs; p += 64) {
             const int i = head + 2 * p;
-            o32[p] = cast_i16_bits(yk[i]) | (cast_i16_bits(yk[i + 1]) << 16);
+            o32[p] = cast_i16x2_bits(yk[i], yk[i + 1]);
         }
         if (pc)
             for (int i = lane; i < block; i += 64) pc[i] = yk[i];
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(64) void fastconv1024_kernel(ConvStream s, long n_o
 // One register row of kept samples: lane l offers the pair (va, vb) = samples (na, na + 1), na = 2 l + 128 d + odd.  With
 // N0 / N1 known when the kernel is built a row is kept whole (one dword store per lane, the usual case), not at all, or
 // partly -- the rows holding the first and the last kept sample: per-lane tests there.  pc (tests only): pre-cast floats.
-template <int N0, int N1>
+template <int N0, int N1, bool PC>
 __device__ __forceinline__ void constexpr_row(int d, int odd, short *obase, unsigned int *p32, float *pc, int lane,
                                               float va, float vb)
 {
@@ -174,15 +174,15 @@ __device__ __forceinline__ void constexpr_row(int d, int odd, short *obase, unsi
     if (first + 128 <= N0 || first >= N1) return;
     const int na = 2 * lane + first;
     if (first >= N0 && first + 128 <= N1) {
-        __builtin_nontemporal_store(cast_i16_bits(va) | (cast_i16_bits(vb) << 16), p32 + 64 * d);
-        if (pc) { pc[na] = va; pc[na + 1] = vb; }
+        __builtin_nontemporal_store(cast_i16x2_bits(va, vb), p32 + 64 * d);
+        if (PC) { pc[na] = va; pc[na + 1] = vb; }
         return;
     }
     const bool ka = na >= N0 && na < N1, kb = na + 1 >= N0 && na + 1 < N1;
-    if (ka && kb) p32[64 * d] = cast_i16_bits(va) | (cast_i16_bits(vb) << 16);
+    if (ka && kb) p32[64 * d] = cast_i16x2_bits(va, vb);
     else if (ka) obase[na] = (short)cast_i16_bits(va);
     else if (kb) obase[na + 1] = (short)cast_i16_bits(vb);
-    if (pc) {
+    if (PC) {
         if (ka) pc[na] = va;
         if (kb) pc[na + 1] = vb;
     }
@@ -203,7 +203,9 @@ __device__ __forceinline__ void constexpr_row(int d, int odd, short *obase, unsi
 #if JDSP_CONV1024_X2 && !JDSP_CONV1024_H_IN_REGS
 #error "JDSP_CONV1024_X2 takes the filter spectra from registers"
 #endif
-template <int NF, int N0, int BLOCK>
+// PC: the pre-cast tap (tests only) is a build-time property of the kernel -- as a run-time test per register row it cut
+// the output stage into two dozen basic blocks that the scheduler could not interleave with anything
+template <int NF, int N0, int BLOCK, bool PC>
 __global__ __launch_bounds__(64, JDSP_CONV1024_MINWAVES) void fastconv1024_pairs_kernel(ConvStream s, long n_out_blocks, int first_block,
                                                                 const float2 *__restrict__ Hall,
                                                                 const float2 *__restrict__ table, short *__restrict__ out,
@@ -267,7 +269,26 @@ __global__ __launch_bounds__(64, JDSP_CONV1024_MINWAVES) void fastconv1024_pairs
             }
         }
     }
+    // A SIMD arbitrates its resident waves by priority, then AGE: with equal priorities the oldest of the three waves a
+    // SIMD holds runs nearly unimpeded and the youngest gets what is left -- of equal static shares a third finished at
+    // 97 us, a third at 122 and a third at 150 (tools/wave_timeline.py, profiles/r03_wave_timeline.txt), the chip a third
+    // empty for the last third of the launch.  Handing the blocks out at run time instead costs an atomic per block
+    // (65,535 returning atomics on one line: 1,030 us).  So every wave walks the priority levels, one step per block:
+    // priority outranks age, each wave does the same number of blocks at each level, and equal shares end together.
+#ifndef JDSP_CONV_PRIO
+#define JDSP_CONV_PRIO 1
+#endif
+    unsigned prio_step = JDSP_CONV_PRIO == 2 ? blockIdx.x % 3u : blockIdx.x >> 10;
     for (long e = blockIdx.x; e < n_out_blocks; e += gridDim.x) {
+#if JDSP_CONV_PRIO
+        {
+            const unsigned lvl = prio_step % 3u;
+            if (lvl == 0) __builtin_amdgcn_s_setprio(0);
+            else if (lvl == 1) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(2);
+            prio_step++;
+        }
+#endif
 #pragma unroll
         for (int r = 0; r < 8; r++) cur[r] = nxt[r];
         if (e + gridDim.x < n_out_blocks) {
@@ -338,19 +359,26 @@ __global__ __launch_bounds__(64, JDSP_CONV1024_MINWAVES) void fastconv1024_pairs
             short *obase = out + (size_t)f * plane + e * block - n0;         // obase[n] = where sample n of the segment goes
             const int odd = (int)((reinterpret_cast<uintptr_t>(obase) >> 1) & 1);  // wave-uniform: which pairing is dword-aligned
             unsigned int *p32 = reinterpret_cast<unsigned int *>(obase + 2 * lane + odd);
-            float *pc = precast ? precast + (size_t)f * plane + e * block - n0 : nullptr;
+            float *pc = PC ? precast + (size_t)f * plane + e * block - n0 : nullptr;
+#if JDSP_CONV_ABLATE & 4                                               /* 4, timing-only: no output stores (one lane keeps the values alive) */
+            if (y[0].x == 1.2345e30f && y[7].y == 5.4321e-30f && y[3].x == y[4].y && y[2].y == y[5].x && y[1].x == y[6].y) {
+                out[lane] = (short)cast_i16_bits(y[0].x + y[1].x + y[2].x + y[3].x + y[4].x + y[5].x + y[6].x + y[7].x +
+                                                 y[0].y + y[1].y + y[2].y + y[3].y + y[4].y + y[5].y + y[6].y + y[7].y);
+            }
+            continue;
+#endif
 #if JDSP_CONV_ABLATE & 2                                               /* 2, timing-only: aligned stores only */
             if (true) {
 #pragma unroll
                 for (int d = 2; d < 8; d++)
-                    __builtin_nontemporal_store(cast_i16_bits(y[d].x) | (cast_i16_bits(y[d].y) << 16),
+                    __builtin_nontemporal_store(cast_i16x2_bits(y[d].x, y[d].y),
                                                 reinterpret_cast<unsigned int *>(out + (size_t)f * plane + e * block + odd) + lane + 64 * (d - 2));
             } else
 #endif
             if (!odd) {
 #pragma unroll
                 for (int d = 0; d < 8; d++) {
-                    constexpr_row<n0, n1>(d, 0, obase, p32, pc, lane, y[d].x, y[d].y);
+                    constexpr_row<n0, n1, PC>(d, 0, obase, p32, pc, lane, y[d].x, y[d].y);
                 }
             } else {
 #pragma unroll
@@ -361,7 +389,7 @@ __global__ __launch_bounds__(64, JDSP_CONV1024_MINWAVES) void fastconv1024_pairs
                         const int first = __builtin_amdgcn_readfirstlane(__float_as_int(y[d < 7 ? d + 1 : d].x));
                         nx = lane == 63 ? first : nx;
                     }
-                    constexpr_row<n0, n1>(d, 1, obase, p32, pc, lane, y[d].y, __int_as_float(nx));
+                    constexpr_row<n0, n1, PC>(d, 1, obase, p32, pc, lane, y[d].y, __int_as_float(nx));
                 }
             }
         }
@@ -530,12 +558,12 @@ int launch_fastconv(hipStream_t st, int n_fft, const ConvStream &s, long n_out_b
         if (n_fft == 1024 && JDSP_CONV1024_PAIRS && (n_filters == 1 || n_filters == 2) && n_taps == 256 && block == 769) {
             // persistent waves (a wave's first block may reach into the history / the silent head: handled there)
             const unsigned grid = (unsigned)(n_out_blocks < JDSP_CONV1024_GRID ? n_out_blocks : JDSP_CONV1024_GRID);
-            if (n_filters == 1)
-                hipLaunchKernelGGL((fastconv1024_pairs_kernel<1, 255, 769>), dim3(grid), dim3(64), 0, st, s, n_out_blocks,
-                                   first_block, H, table, out, precast, plane, s.hist_len > 0 ? hist_out : (short *)nullptr);
-            else
-                hipLaunchKernelGGL((fastconv1024_pairs_kernel<2, 255, 769>), dim3(grid), dim3(64), 0, st, s, n_out_blocks,
-                                   first_block, H, table, out, precast, plane, s.hist_len > 0 ? hist_out : (short *)nullptr);
+            short *ho = s.hist_len > 0 ? hist_out : (short *)nullptr;
+#define JDSP_LAUNCH_PAIRS(NF_, PC_) hipLaunchKernelGGL((fastconv1024_pairs_kernel<NF_, 255, 769, PC_>), dim3(grid), dim3(64), 0, st, s, \
+                                                       n_out_blocks, first_block, H, table, out, precast, plane, ho)
+            if (n_filters == 1) { if (precast) JDSP_LAUNCH_PAIRS(1, true); else JDSP_LAUNCH_PAIRS(1, false); }
+            else { if (precast) JDSP_LAUNCH_PAIRS(2, true); else JDSP_LAUNCH_PAIRS(2, false); }
+#undef JDSP_LAUNCH_PAIRS
             return hipGetLastError() == hipSuccess ? 0 : -1;
         } else if (n_fft == 1024)
             hipLaunchKernelGGL(fastconv1024_kernel, dim3((unsigned)n_out_blocks), dim3(64), 0, st, s, n_out_blocks,
@@ -674,7 +702,7 @@ __global__ __launch_bounds__(64) void fastconv_upols_kernel(const float2 *__rest
 #pragma unroll
         for (int d = 0; d < 4; d++) {
             const float2 v = make_float2(y[d + 4].x * (1.0f / 1024.0f), y[d + 4].y * (1.0f / 1024.0f));
-            __builtin_nontemporal_store(cast_i16_bits(v.x) | (cast_i16_bits(v.y) << 16), o + 64 * d);
+            __builtin_nontemporal_store(cast_i16x2_bits(v.x, v.y), o + 64 * d);
             if (pc) *reinterpret_cast<float2 *>(pc + 2 * lane + 128 * d) = v;
         }
     }
@@ -799,7 +827,7 @@ __global__ __launch_bounds__(kUpolsWaves * 64) void fastconv_upols4_kernel(const
 #pragma unroll
                 for (int d = 0; d < 4; d++) {
                     const float2 v = make_float2(y[d + 4].x * (1.0f / 1024.0f), y[d + 4].y * (1.0f / 1024.0f));
-                    __builtin_nontemporal_store(cast_i16_bits(v.x) | (cast_i16_bits(v.y) << 16), o + 64 * d);
+                    __builtin_nontemporal_store(cast_i16x2_bits(v.x, v.y), o + 64 * d);
                     if (pc) *reinterpret_cast<float2 *>(pc + 2 * lane + 128 * d) = v;
                 }
             }

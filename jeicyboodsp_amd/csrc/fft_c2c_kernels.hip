@@ -335,6 +335,9 @@ __device__ __forceinline__ void cd_powers(const cd &b, cd (&p)[8])
 #ifndef JDSP_F64_PLAIN_STORES
 #define JDSP_F64_PLAIN_STORES 0
 #endif
+#ifndef JDSP_F64_LINEAR_MAP
+#define JDSP_F64_LINEAR_MAP 1
+#endif
 template <bool DW>
 __global__ __launch_bounds__(64, 4) void stft1024_f64_v2_kernel(const short *__restrict__ pcm, long n_frames, long hop,
                                                                const double *__restrict__ table,
@@ -343,8 +346,15 @@ __global__ __launch_bounds__(64, 4) void stft1024_f64_v2_kernel(const short *__r
 {
     __shared__ __attribute__((aligned(16))) cd lds[kFft512Lds];
     const int lane = threadIdx.x;
-    const long per_xcd = (gridDim.x + 7) >> 3;            // XCD-aware order: neighbouring frames share an XCD's L2
+    // Frames in dispatch order: behind the read pass the PCM comes out of the Infinity Cache whichever XCD asks, and the
+    // eight XCDs then write ONE moving 128 KB window of the output instead of eight streams 128 MiB apart
+    // (196-198 us against 204 for the XCD-contiguous order of the FP32 path's no-read-pass days: profiles/r03_stft_f64.txt)
+#if JDSP_F64_LINEAR_MAP
+    const long t0 = (long)blockIdx.x * run;
+#else
+    const long per_xcd = (gridDim.x + 7) >> 3;
     const long t0 = ((long)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3)) * run;
+#endif
     if (t0 >= n_frames) return;
     const long t1 = t0 + run < n_frames ? t0 + run : n_frames;
     double2 win[8];

@@ -29,6 +29,12 @@ __device__ __forceinline__ unsigned int cast_i16_bits(float v)
 {
     return (unsigned int)((int)v) & 0xffffu;
 }
+// two of them in one dword, a in the low half: the two truncations and ONE v_perm_b32 that picks the low 16 bits of each
+// (cast | cast << 16 compiles to v_and + v_lshl_or: four instructions per sample pair instead of three)
+__device__ __forceinline__ unsigned int cast_i16x2_bits(float a, float b)
+{
+    return __builtin_amdgcn_perm((unsigned int)(int)b, (unsigned int)(int)a, 0x05040100u);
+}
 
 // Forward split of the packed transform: Zh = FFT512(z)/2 (the 1/2 is folded into the
 // window).  E = Zh[m] + conj(Zh[512-m]),  O = -j (Zh[m] - conj(Zh[512-m])),
