@@ -941,6 +941,9 @@ __global__ __launch_bounds__(64, JDSP_DENOISE_MINWAVES) void denoise_kernel(
 #ifndef JDSP_DENOISE_RESIDENT
 #define JDSP_DENOISE_RESIDENT (JDSP_DENOISE_PAIRS ? 4 : 3)      // waves per SIMD the run kernel's register budget allows
 #endif
+#ifndef JDSP_DENOISE_TAKE_EARLY
+#define JDSP_DENOISE_TAKE_EARLY 1                                // 1: the prefetched block is taken before this block's stores, not after them
+#endif
 #ifndef JDSP_DENOISE_PRIO
 #define JDSP_DENOISE_PRIO 1                                      // 1: the run kernels' waves rotate through the priority levels
 #endif
@@ -1003,6 +1006,12 @@ __global__ __launch_bounds__(64, JDSP_DENOISE_RESIDENT) void denoise_run_kernel(
     // every wave walks the priority levels, one step per block (see fastconv1024_pairs_kernel: a SIMD serves equal-priority
     // waves by age, and equal shares then finish far apart)
     unsigned prio_step = blockIdx.x >> 10;
+    // vmcnt counts loads and stores together, in issue order, and across the loop's back edge the compiler waits for
+    // vmcnt(0): taking the prefetched block at the TOP of an iteration waited for the previous block's output stores to
+    // complete, every block.  It is taken (tk <- nxt) just before this block's stores instead (see fastconv1024_pairs_kernel).
+    unsigned int tk[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) tk[r] = nxt[r];
     for (long j = j0; j < j1; j++) {
 #if JDSP_DENOISE_PRIO
         switch (prio_step++ & 3u) {
@@ -1014,7 +1023,7 @@ __global__ __launch_bounds__(64, JDSP_DENOISE_RESIDENT) void denoise_run_kernel(
 #endif
         unsigned int cur[4];
 #pragma unroll
-        for (int r = 0; r < 4; r++) { cur[r] = nxt[r]; raw[r] = raw[r + 4]; raw[r + 4] = nxt[r]; }
+        for (int r = 0; r < 4; r++) { cur[r] = tk[r]; raw[r] = raw[r + 4]; raw[r + 4] = tk[r]; }
         if (j + 1 < j1) load_block_pairs(pcm, n_blocks, st_in, j + 1, lane, nxt);      // needed one iteration from now
         if (calls_before + j == 0) {
 #pragma unroll
@@ -1033,6 +1042,11 @@ __global__ __launch_bounds__(64, JDSP_DENOISE_RESIDENT) void denoise_run_kernel(
             o[d] = make_float2(tail[d].x + y[d].x, tail[d].y + y[d].y);      // SS:248 overlap-add
             tail[d] = y[d + 4];                                               // SS:255-256
         }
+#if JDSP_DENOISE_TAKE_EARLY
+#pragma unroll
+        for (int r = 0; r < 4; r++) { tk[r] = nxt[r]; asm volatile("" : "+v"(tk[r])); }
+        __builtin_amdgcn_sched_barrier(0);
+#endif
         if (j >= first_emit && j < sh.emit_to) {
             const long oi = j - first_emit;
             unsigned int *dst = reinterpret_cast<unsigned int *>(out + oi * 512) + lane;
@@ -1050,6 +1064,10 @@ __global__ __launch_bounds__(64, JDSP_DENOISE_RESIDENT) void denoise_run_kernel(
 #pragma unroll
             for (int d = 0; d < 4; d++) *reinterpret_cast<float2 *>(&st_out->tail[2 * lane + 128 * d]) = tail[d];
         }
+#if !JDSP_DENOISE_TAKE_EARLY
+#pragma unroll
+        for (int r = 0; r < 4; r++) tk[r] = nxt[r];
+#endif
     }
 }
 
@@ -1677,6 +1695,15 @@ __global__ __launch_bounds__(64, JDSP_DENOISE512_WAVES(MODE)) void denoise512_ru
             ob[d] = tail[d] + (b_void ? 0.f : y[d].y);
             tail_b[d] = b_void ? 0.f : y[d + 4].y;
         }
+#if JDSP_DENOISE_TAKE_EARLY
+        if (ja + 2 < j1) {                                        // the next pair's samples are taken before this pair's stores
+#pragma unroll
+            for (int b = 0; b < 2; b++)
+#pragma unroll
+                for (int t = 0; t < 4; t++) asm volatile("" : "+v"(nx[b][t]));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#endif
 #pragma unroll
         for (int half = 0; half < 2; half++) {
             const long j = half ? jb : ja;

@@ -157,6 +157,9 @@ __global__ __launch_bounds__(64) void fastconv1024_kernel(ConvStream s, long n_o
 #ifndef JDSP_CONV1024_PAIRS
 #define JDSP_CONV1024_PAIRS 1
 #endif
+#ifndef JDSP_CONV_PLAIN_STORES
+#define JDSP_CONV_PLAIN_STORES 0
+#endif
 #ifndef JDSP_CONV_ABLATE
 #define JDSP_CONV_ABLATE 0          // timing-only ablations of fastconv1024_pairs_kernel (tools/build_variant.sh): wrong results
 #endif
@@ -174,7 +177,16 @@ __device__ __forceinline__ void constexpr_row(int d, int odd, short *obase, unsi
     if (first + 128 <= N0 || first >= N1) return;
     const int na = 2 * lane + first;
     if (first >= N0 && first + 128 <= N1) {
+#if JDSP_CONV_ABLATE & 8                                          /* 8, timing-only: casts and packing stay, the row stores never execute */
+        const unsigned int pk = cast_i16x2_bits(va, vb);
+        if (pk == 0xdeadbeefu && __builtin_amdgcn_readfirstlane((int)pk) == 123) p32[64 * d] = pk;
+        return;
+#endif
+#if JDSP_CONV_PLAIN_STORES                                        /* timing-only A/B: cached stores (L2 merges the partial lines of the odd-pitch rows) */
+        p32[64 * d] = cast_i16x2_bits(va, vb);
+#else
         __builtin_nontemporal_store(cast_i16x2_bits(va, vb), p32 + 64 * d);
+#endif
         if (PC) { pc[na] = va; pc[na + 1] = vb; }
         return;
     }
@@ -279,6 +291,18 @@ __global__ __launch_bounds__(64, JDSP_CONV1024_MINWAVES) void fastconv1024_pairs
 #define JDSP_CONV_PRIO 1
 #endif
     unsigned prio_step = JDSP_CONV_PRIO == 2 ? blockIdx.x % 3u : blockIdx.x >> 10;
+    // vmcnt counts loads and stores together, in issue order, and across the loop's back edge the compiler waits for
+    // vmcnt(0): taking the prefetched samples at the TOP of an iteration therefore waited for the previous block's two
+    // dozen output stores to complete, every block.  They are taken (cur <- nxt) just BEFORE this block's stores instead:
+    // the loads were issued a whole block's arithmetic earlier, and the stores then have until the next block's take.
+#ifndef JDSP_CONV_TAKE_EARLY
+#define JDSP_CONV_TAKE_EARLY 1
+#endif
+    constexpr bool take_early = JDSP_CONV_TAKE_EARLY && NF == 2 && JDSP_CONV1024_X2;   // (the one-filter form stores inside its filter loop)
+    if (take_early) {
+#pragma unroll
+        for (int r = 0; r < 8; r++) cur[r] = nxt[r];
+    }
     for (long e = blockIdx.x; e < n_out_blocks; e += gridDim.x) {
 #if JDSP_CONV_PRIO
         {
@@ -289,8 +313,10 @@ __global__ __launch_bounds__(64, JDSP_CONV1024_MINWAVES) void fastconv1024_pairs
             prio_step++;
         }
 #endif
+        if (!take_early) {
 #pragma unroll
-        for (int r = 0; r < 8; r++) cur[r] = nxt[r];
+            for (int r = 0; r < 8; r++) cur[r] = nxt[r];
+        }
         if (e + gridDim.x < n_out_blocks) {
             const short *src = s.pcm + ((long)(first_block + e + gridDim.x + 1) * block - 1024) + 2 * lane;
 #pragma unroll
@@ -334,6 +360,11 @@ __global__ __launch_bounds__(64, JDSP_CONV1024_MINWAVES) void fastconv1024_pairs
             wave_fft512_x2_staggered<true>(yy[0], yy[NF - 1], lds, lds_b, lane, tw);
         }
 #endif
+        if (take_early) {
+#pragma unroll
+            for (int r = 0; r < 8; r++) { cur[r] = nxt[r]; asm volatile("" : "+v"(cur[r])); }
+            __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int f = 0; f < NF; f++) {
             float2 (&y)[8] = yy[f];

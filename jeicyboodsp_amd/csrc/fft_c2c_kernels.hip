@@ -338,7 +338,8 @@ __device__ __forceinline__ void cd_powers(const cd &b, cd (&p)[8])
 #ifndef JDSP_F64_LINEAR_MAP
 #define JDSP_F64_LINEAR_MAP 1
 #endif
-template <bool DW>
+// LOOP: a wave walks `run` > 1 frames (prefetch of the next frame, taken before this frame's stores); !LOOP: one frame per wave
+template <bool DW, bool LOOP>
 __global__ __launch_bounds__(64, 4) void stft1024_f64_v2_kernel(const short *__restrict__ pcm, long n_frames, long hop,
                                                                const double *__restrict__ table,
                                                                const double2 *__restrict__ tw, double2 *__restrict__ out,
@@ -356,7 +357,7 @@ __global__ __launch_bounds__(64, 4) void stft1024_f64_v2_kernel(const short *__r
     const long t0 = ((long)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3)) * run;
 #endif
     if (t0 >= n_frames) return;
-    const long t1 = t0 + run < n_frames ? t0 + run : n_frames;
+    const long t1 = LOOP ? (t0 + run < n_frames ? t0 + run : n_frames) : t0 + 1;
     double2 win[8];
     {
         const double2 *wp = reinterpret_cast<const double2 *>(table) + lane;
@@ -382,16 +383,19 @@ __global__ __launch_bounds__(64, 4) void stft1024_f64_v2_kernel(const short *__r
         }
     };
     fetch(t0);
+    unsigned int tk[8];                                   // DW: the frame's samples as taken from `raw` (see below)
+#pragma unroll
+    for (int r = 0; r < 8; r++) tk[r] = raw[r];
 #pragma unroll 1
     for (long t = t0; t < t1; t++) {
         cd v[8];
 #pragma unroll
         for (int r = 0; r < 8; r++) {
-            const int s0 = DW ? (int)(short)(raw[r] & 0xffffu) : (int)raw16[2 * r];
-            const int s1 = DW ? ((int)raw[r] >> 16) : (int)raw16[2 * r + 1];
+            const int s0 = DW ? (int)(short)(tk[r] & 0xffffu) : (int)raw16[2 * r];
+            const int s1 = DW ? ((int)tk[r] >> 16) : (int)raw16[2 * r + 1];
             v[r] = {(double)s0 * win[r].x, (double)s1 * win[r].y};
         }
-        if (t + 1 < t1) fetch(t + 1);                     // in flight across this frame's arithmetic and stores
+        if (LOOP && t + 1 < t1) fetch(t + 1);             // in flight across this frame's arithmetic
         cd_opaque(b1); cd_opaque(b2); cd_opaque(b3);
         cd_dft8<false>(v);
         {
@@ -438,6 +442,14 @@ __global__ __launch_bounds__(64, 4) void stft1024_f64_v2_kernel(const short *__r
         for (int d = 0; d < 8; d++) lds[lane + 64 * d] = v[d];
         if (lane == 0) lds[512] = v[0];
         lds_fence_wave();
+        // the next frame's samples are taken BEFORE this frame's stores: vmcnt counts loads and stores together in issue
+        // order and the loop's back edge waits for vmcnt(0), so taking them at the top of the next iteration waited for
+        // these sixteen 1 KB stores to complete (see fastconv1024_pairs_kernel)
+        if (LOOP && DW && t + 1 < t1) {
+#pragma unroll
+            for (int r = 0; r < 8; r++) { tk[r] = raw[r]; asm volatile("" : "+v"(tk[r])); }
+            __builtin_amdgcn_sched_barrier(0);
+        }
         typedef double f64x2 __attribute__((ext_vector_type(2)));
         f64x2 *dst = reinterpret_cast<f64x2 *>(out + t * 1024 + lane);
         // W16^d = exp(-2 pi j d / 16)
@@ -478,12 +490,14 @@ int launch_stft1024_f64(hipStream_t stream, int n_cu, const short *pcm, long n_f
     if (variant == 1)
         hipLaunchKernelGGL(stft1024_f64_kernel, dim3((unsigned)grid), dim3(64), 0, stream, pcm, n_frames, hop, table, tw512,
                            out, (int)run);
-    else if ((((uintptr_t)pcm) & 3u) == 0 && (hop & 1) == 0)
-        hipLaunchKernelGGL(stft1024_f64_v2_kernel<true>, dim3((unsigned)grid), dim3(64), 0, stream, pcm, n_frames, hop, table,
-                           tw512, out, (int)run);
-    else
-        hipLaunchKernelGGL(stft1024_f64_v2_kernel<false>, dim3((unsigned)grid), dim3(64), 0, stream, pcm, n_frames, hop, table,
-                           tw512, out, (int)run);
+    else {
+        const bool dw = (((uintptr_t)pcm) & 3u) == 0 && (hop & 1) == 0;
+#define JDSP_F64_LAUNCH(DW_, LOOP_) hipLaunchKernelGGL((stft1024_f64_v2_kernel<DW_, LOOP_>), dim3((unsigned)grid), dim3(64), 0, stream, pcm, \
+                                                       n_frames, hop, table, tw512, out, (int)run)
+        if (run > 1) { if (dw) JDSP_F64_LAUNCH(true, true); else JDSP_F64_LAUNCH(false, true); }
+        else { if (dw) JDSP_F64_LAUNCH(true, false); else JDSP_F64_LAUNCH(false, false); }
+#undef JDSP_F64_LAUNCH
+    }
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

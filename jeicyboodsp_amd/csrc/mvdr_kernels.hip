@@ -417,6 +417,52 @@ __global__ __launch_bounds__(256) void mvdr_weights_kernel(const DenoisePlan *__
         wtab[(size_t)ver * 1024 + bin] = mvdr_bin_weights(mvdr_inverse(rver + (size_t)ver * 4), s1);
 }
 
+// ---- the beamformer's frame straight from the two blocks' dwords (round 3): no LDS staging ----------------------------
+// frame = [first 511 samples of the previous block, block, 0] (BF:136-141,:195-196); lane l transforms the sample pairs
+// (2 l + 128 r, + 1), r < 8.  With P / C the previous / current block as 256 dwords each:
+//   r < 3, and r = 3 for l < 63:  the pair is the dword P[l + 64 r]                                  (positions < 510)
+//   r = 3, l = 63              :  (P[255] low half, C[0] low half)                                   (positions 510, 511)
+//   r >= 4                     :  position p = 2 l + 128 r holds block sample 2 l + 128 (r - 4) + 1: the pair is
+//                                 (high half of C[k], low half of C[k + 1]), k = l + 64 (r - 4) -- C[k + 1] is the next lane's
+//                                 dword (DPP wave_shl:1; lane 63: lane 0's next register, and nothing after C[255]: the 0)
+// Eight coalesced dword loads per channel, four DPP moves and four v_alignbit: the 16-byte-per-lane load images went
+// through LDS for this (2 ds_write_b128 + 13 ds_read_b32 per channel and two fences).
+__device__ __forceinline__ void mvdr_load_block32(const short *__restrict__ pcm, long n_blocks, const short *__restrict__ prev,
+                                                  long j, int lane, unsigned int (&d)[4])
+{
+    const unsigned int *src = nullptr;
+    if (j >= 0 && j < n_blocks) src = reinterpret_cast<const unsigned int *>(pcm + j * 512);
+    else if (j == -1) src = reinterpret_cast<const unsigned int *>(prev);
+#pragma unroll
+    for (int r = 0; r < 4; r++) d[r] = src ? src[lane + 64 * r] : 0u;
+}
+
+__device__ __forceinline__ void mvdr_frame_pairs_direct(const unsigned int (&P)[4], const unsigned int (&C)[4], int lane,
+                                                        float2 (&v)[8], float scale)
+{
+    const unsigned int c0 = (unsigned int)__builtin_amdgcn_readfirstlane((int)C[0]);
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        unsigned int pr = P[r];
+        if (r == 3) pr = lane == 63 ? ((P[3] & 0xffffu) | (c0 << 16)) : P[3];
+        const float2 a = unpack_i16x2(pr);
+        v[r] = make_float2(scale * a.x, scale * a.y);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        unsigned int nx = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)C[r], 0x130, 0xf, 0xf, true);   // wave_shl:1, lane 63 <- 0
+        if (r < 3) {
+            const unsigned int first = (unsigned int)__builtin_amdgcn_readfirstlane((int)C[r < 3 ? r + 1 : r]);
+            nx = lane == 63 ? first : nx;
+        }
+        const float2 a = unpack_i16x2(__builtin_amdgcn_alignbit(nx, C[r], 16));   // (C >> 16) | (next << 16)
+        v[r + 4] = make_float2(scale * a.x, scale * a.y);
+    }
+}
+
+#ifndef JDSP_MVDR_DIRECT
+#define JDSP_MVDR_DIRECT 1      // 1: frames from dwords in registers, both forward transforms staggered in one wave, dword output stores
+#endif
 __global__ __launch_bounds__(64) void mvdr_pairs_kernel(const short *__restrict__ left, const short *__restrict__ right,
                                                         long n_blocks, long calls_before,
                                                         const MvdrState *__restrict__ st_in, MvdrState *st_out,
@@ -427,8 +473,13 @@ __global__ __launch_bounds__(64) void mvdr_pairs_kernel(const short *__restrict_
                                                         float *__restrict__ precast, DenoiseShard sh,
                                                         const DenoisePlan *__restrict__ plan, const float4 *__restrict__ wtab)
 {
+#if JDSP_MVDR_DIRECT
+    __shared__ __attribute__((aligned(16))) float2 lds2[2][kWaveLdsComplex];
+    float2 *lds = lds2[0];
+#else
     __shared__ __attribute__((aligned(16))) float2 lds[kWaveLdsComplex];
     __shared__ __attribute__((aligned(16))) unsigned int stage32[528];
+#endif
     const int lane = threadIdx.x;
     const long per_xcd = (gridDim.x + 7) >> 3;
     const long j = (long)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
@@ -441,6 +492,38 @@ __global__ __launch_bounds__(64) void mvdr_pairs_kernel(const short *__restrict_
     const long jp = have_prev ? j - 1 : -2;          // keep buffer of a stream's very first block: zeros (:130-131)
 
     float2 llo[5], lhi[5], rlo[5], rhi[5], v[8], zr[5];
+#if JDSP_MVDR_DIRECT
+    {
+        unsigned int lp[4], lc[4], rp[4], rc[4];
+        mvdr_load_block32(left, n_blocks, st_in->prev_l, jp, lane, lp);
+        mvdr_load_block32(left, n_blocks, st_in->prev_l, j, lane, lc);
+        mvdr_load_block32(right, n_blocks, st_in->prev_r, jp, lane, rp);
+        mvdr_load_block32(right, n_blocks, st_in->prev_r, j, lane, rc);
+        float2 vr[8], zq[5];
+        mvdr_frame_pairs_direct(lp, lc, lane, v, 0.5f);
+        mvdr_frame_pairs_direct(rp, rc, lane, vr, 0.5f);
+        wave_fft512_x2_staggered<false>(v, vr, lds2[0], lds2[1], lane, tw);
+        // both channels' mirror operands in one round trip
+#pragma unroll
+        for (int d = 3; d < 8; d++) { lds2[0][lane + 64 * d] = v[d]; lds2[1][lane + 64 * d] = vr[d]; }
+        if (lane == 0) { lds2[0][512] = v[0]; lds2[1][512] = vr[0]; }
+        wave_lds_fence();
+#pragma unroll
+        for (int d = 0; d < 5; d++) { zr[d] = lds2[0][512 - lane - 64 * d]; zq[d] = lds2[1][512 - lane - 64 * d]; }
+        wave_lds_fence();
+#pragma unroll
+        for (int d = 0; d < 5; d++) {
+            const float2 e = cadd_conj(v[d], zr[d]), o = csub_conj_mj(v[d], zr[d]);
+            const float2 t = cmul(pw.w[d], o);
+            llo[d] = cadd(e, t);
+            lhi[d] = csub(e, t);
+            const float2 e2 = cadd_conj(vr[d], zq[d]), o2 = csub_conj_mj(vr[d], zq[d]);
+            const float2 t2 = cmul(pw.w[d], o2);
+            rlo[d] = cadd(e2, t2);
+            rhi[d] = csub(e2, t2);
+        }
+    }
+#else
 #if JDSP_MVDR_EARLY_LOADS
     // the right channel's blocks are requested before the left channel's transform (whose LDS fences would hold the loads back)
     const u32x4 r_prev = mvdr_load_block(right, n_blocks, st_in->prev_r, jp, lane);
@@ -479,6 +562,7 @@ __global__ __launch_bounds__(64) void mvdr_pairs_kernel(const short *__restrict_
         rhi[d] = csub(e, t);
     }
 #endif
+#endif   // JDSP_MVDR_DIRECT
     // the matrix in effect at this block (looking it up ahead of the transforms instead measured the same)
 #if JDSP_MVDR_ABLATE == 4                                   // timing only: no version lookup
     int ver = 0;
@@ -522,6 +606,29 @@ __global__ __launch_bounds__(64) void mvdr_pairs_kernel(const short *__restrict_
     wave_fft512<true>(y, lds, lane, tw);
 
     const long first_emit = sh.emit_from;                           // :201-204: the first call's block is dropped
+#if JDSP_MVDR_DIRECT
+    if (j >= first_emit && j < sh.emit_to) {
+        // :193 rgsOutputBuffer[i] = y[i + 511] / 1024: output sample i = n - 511.  Lane l holds y[n], y[n + 1] for n = 2 l + 128 dd;
+        // the dword-aligned output pairs are (n odd, n + 1): this lane's .y and the next lane's .x (lane 63: lane 0's next
+        // register) -- five dword stores per block instead of sixteen 2-byte ones.
+        unsigned int *o32 = reinterpret_cast<unsigned int *>(out + (j - first_emit) * 512);
+        float *pc = precast ? precast + (j - first_emit) * 512 : nullptr;
+#pragma unroll
+        for (int dd = 3; dd < 8; dd++) {
+            float nx = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(y[dd].x), 0x130, 0xf, 0xf, true));   // wave_shl:1
+            if (dd < 7) {
+                const float first = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(y[dd < 7 ? dd + 1 : dd].x)));
+                nx = lane == 63 ? first : nx;
+            }
+            const float s0 = y[dd].y * (1.0f / 1024.0f), s1 = nx * (1.0f / 1024.0f);
+            const int i0 = 2 * lane + 128 * dd - 510;                // even; the pair (i0, i0 + 1)
+            if (i0 >= 0 && i0 < 512) {
+                o32[i0 >> 1] = cast_i16x2_bits(s0, s1);
+                if (pc) { pc[i0] = s0; pc[i0 + 1] = s1; }
+            }
+        }
+    }
+#else
     if (j >= first_emit && j < sh.emit_to) {
         short *o = out + (j - first_emit) * 512;
         float *pc = precast ? precast + (j - first_emit) * 512 : nullptr;
@@ -533,6 +640,7 @@ __global__ __launch_bounds__(64) void mvdr_pairs_kernel(const short *__restrict_
             if (i0 + 1 >= 0 && i0 + 1 < 512) { o[i0 + 1] = (short)cast_i16_bits(s1); if (pc) pc[i0 + 1] = s1; }
         }
     }
+#endif
     if (j == n_blocks - 1) {
         reinterpret_cast<u32x4 *>(st_out->prev_l)[lane] = reinterpret_cast<const u32x4 *>(left + j * 512)[lane];
         reinterpret_cast<u32x4 *>(st_out->prev_r)[lane] = reinterpret_cast<const u32x4 *>(right + j * 512)[lane];

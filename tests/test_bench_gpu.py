@@ -65,3 +65,36 @@ def test_gpus_two_starts_its_own_ranks_and_runs_the_kernels():
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0
     assert line["config"]["frames_per_gpu"] == 256 and "cpu_baseline" not in line
     assert line["gather"]["ms"] > 0 and "gloo" in line["gather"]["transport"]
+
+
+def test_default_line_carries_the_fp64_leg():
+    """roofline.fp64: the same K steps through jdsp_stft_i16_f64_dev (the reference's own precision, complex128 out,
+    17,408 algorithmic bytes per frame), timed after the reported leg."""
+    r = subprocess.run([sys.executable, BENCH, "--frames", "4096", "--steps", "10", "--warmup", "3", "--no-cpu-baseline"],
+                       env=_clean_env(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    f = _one_json_line(r)["roofline"]["fp64"]
+    assert f["dtype"] == "f64" and f["algorithmic_bytes_per_launch"] == 4096 * (512 * 2 + 1024 * 16)
+    assert f["kernel_ms"] > 0 and abs(f["achieved"] - f["algorithmic_bytes_per_launch"] / (f["kernel_ms"] * 1e-3) / 1e9) < 1e-6 * f["achieved"]
+    r = subprocess.run([sys.executable, BENCH, "--frames", "4096", "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--no-fp64-leg"],
+                       env=_clean_env(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert "fp64" not in _one_json_line(r)["roofline"]
+
+
+@pytest.mark.parametrize("gpus", [1, 2])
+def test_mfcc10k_workload_is_rank_aware(gpus):
+    """`--workload mfcc10k` = BASELINE config 4: the 10,000-utterance MFCC batch split by whole utterances over the
+    ranks (strong scaling).  One rank, and two self-launched ranks sharing this box's one GPU (gloo): the same total
+    frame count, rank 0 holding all of it or about half."""
+    cmd = [sys.executable, BENCH, "--workload", "mfcc10k", "--gpus", str(gpus), "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+    if gpus > 1:
+        cmd += ["--backend", "gloo"]
+    r = subprocess.run(cmd, env=_clean_env(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    line = _one_json_line(r)
+    assert line["n_gpus"] == gpus and line["scaling"] == "strong" and line["unit"] == "frames/s" and line["value"] > 0
+    assert "10,000" in line["config"]["workload"] and "utterance-sharded x%d" % gpus in line["config"]["parallelism"]
+    total = 3_000_000
+    if gpus == 1:
+        assert line["config"]["utterances_rank0"] == 10000 and 3_000_000 < line["config"]["frames_rank0"] < 4_000_000
+    else:
+        assert 4000 < line["config"]["utterances_rank0"] < 6000 and total / 2 * 0.9 < line["config"]["frames_rank0"] < 2_100_000
+    assert line["roofline"]["bound"] == "hbm" and line["roofline"]["algorithmic_bytes_per_launch"] == 424 * line["config"]["frames_rank0"]

@@ -79,3 +79,34 @@ def test_two_handles_are_independent(eng):
     assert np.array_equal(np.concatenate(outs_b), ref_b.process(b))
     for o in (da, db, ref_a, ref_b):
         o.close()
+
+
+def test_vad_trace_follows_the_option_at_the_time_of_the_call(eng):
+    """jdsp_denoise_vad_trace hands out energies / zero-crossing counts only if "vad_trace" was set when the traced
+    call RAN (ABI version 2): setting it afterwards must not expose buffers that call never filled."""
+    import jeicyboodsp_amd
+    rng = np.random.default_rng(3)
+    pcm = np.clip(np.rint(rng.normal(0, 3000, 8 * 512)), -32768, 32767).astype(np.int16)
+    d = eng.denoiser(0)
+    d.process(pcm)                                                    # option off: flags only
+    assert d.vad_trace(8, flags_only=True).shape == (8,)
+    d.set_option("vad_trace", 1)                                      # ... switched on AFTER the call
+    with pytest.raises(jeicyboodsp_amd.JdspError):
+        d.vad_trace(8)
+    d.process(pcm)                                                    # a call that ran with it on
+    v, e, z = d.vad_trace(8)
+    assert v.shape == e.shape == z.shape == (8,) and (e > 0).all()
+    d.set_option("vad_trace", 0)
+    v2, e2, z2 = d.vad_trace(8)                                       # still that call's trace
+    assert np.array_equal(e2, e)
+    d.close()
+    assert jeicyboodsp_amd._lib.lib.jdsp_abi_version() == 2
+
+
+def test_stft_options_take_documented_values_only(eng):
+    for name, bad in (("stft.read_pass", 2), ("stft.f64_kernel", 2), ("stft.f64_frames_per_wave", -1)):
+        with pytest.raises(Exception):
+            eng.set_option(name, bad)
+    eng.set_option("stft.f64_kernel", 1)
+    eng.set_option("stft.f64_kernel", 0)
+    eng.set_option("stft.f64_frames_per_wave", 0)
