@@ -1,6 +1,6 @@
 // compat_selftest.cpp -- drives the reference-signature functions exactly the way the
 // reference main()s do (one block per call) and dumps what they return, for tests/ to compare
-// with the CPU checker.  usage: compat_selftest <ss|wf|vad|conv|mfcc|mfccsteps|pitch|awgn|fft|dft|gmm|prob|hmm> in.raw out.bin [taps.f64 | params.bin]
+// with the CPU checker.  usage: compat_selftest <ss|wf|noise|vad|conv|mfcc|mfccsteps|pitch|awgn|fft|dft|gmm|prob|hmm> in.raw out.bin [taps.f64 | params.bin]
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -40,6 +40,24 @@ int main(int argc, char **argv)
             } else iter = 0;
             bool ok = !strcmp(what, "ss") ? SpectralSubtraction(in, noise, ob, B) : WienerFiltering(in, noise, ob, B);
             if (ok) fwrite(ob, 2, B, out);
+        }
+    } else if (!strcmp(what, "noise")) {
+        // EstimateNoiseSpectrum by name (SS:159-198): main()'s VAD / run-length logic around it (SS:98-109), and
+        // pdEstimatedNoiseSpec dumped every time it is latched (iNumOfIteration == 10, :189-193); argv[4] = BLOCK_LEN
+        const int B = argc > 4 ? atoi(argv[4]) : 512;
+        short temp[512] = {0};
+        double noise[1024] = {0};
+        int iter = 0;
+        for (size_t b = 0; b + B <= pcm.size(); b += B) {
+            short *in = &pcm[b];
+            if (!VoiceActivityDetection(in, B)) {
+                iter++;
+                if (iter == 1) memcpy(temp, in, sizeof(short) * B);
+                else if (iter > 1) {
+                    EstimateNoiseSpectrum(temp, iter, in, noise, B);
+                    if (iter == 10) fwrite(noise, 8, 2 * B, out);
+                }
+            } else iter = 0;
         }
     } else if (!strcmp(what, "vad")) {
         // VoiceActivityDetection (SS:121-156) alone, one byte per block; argv[4] = BLOCK_LEN (default 512)

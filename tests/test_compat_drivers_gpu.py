@@ -443,3 +443,26 @@ def test_compat_denoise_per_block_calls_with_iframecount_256(tmp_path, oracle, w
     assert len(noises) >= 3 and 0 < flags.sum() < n_blocks                # estimates were latched; both VAD outcomes occur
     assert got.shape == want.shape == ((n_blocks - 2) * 256,)
     assert np.abs(got.astype(np.int32) - want.astype(np.int32)).max() <= 1
+
+
+@pytest.mark.parametrize("block", [512, 256])
+def test_compat_estimate_noise_spectrum_by_name(tmp_path, oracle, block):
+    """EstimateNoiseSpectrum of the compat layer (SS:159-198: the frame's transform on the GPU in FP32, the running
+    magnitude average and the latch on the host in FP64) against the oracle's latched estimates, one by one."""
+    rng = np.random.default_rng(5 + block)
+    n_blocks = 120
+    alt = np.where(np.arange(block) % 2 == 0, 1.0, -1.0)
+    x = rng.normal(0, 3000, n_blocks * block)
+    for b0, n in ((0, 14), (30, 12), (60, 25), (100, 11)):                 # four quiet runs of >= 10 blocks: four latches
+        q = rng.normal(0, 30, (n, block))
+        if block == 256:
+            q = (np.abs(q) + 14.0) * alt                                  # ZCR >= 200 needs a sign change at nearly every sample
+        x[b0 * block:(b0 + n) * block] = q.ravel()
+    pcm = np.clip(np.rint(x), -32768, 32767).astype(np.int16)
+    pcm.tofile(tmp_path / "in.raw")
+    run("compat_selftest", "noise", tmp_path / "in.raw", tmp_path / "noise.bin", block)
+    got = np.fromfile(tmp_path / "noise.bin", np.float64).reshape(-1, 2 * block)
+    _, _, _, noises, _ = oracle.denoise_trace(0, pcm, block=block)
+    want = noises[1:]                                                     # [0] is the all-zero start
+    assert got.shape == want.shape and want.shape[0] == 4
+    assert (np.abs(got - want).max(axis=1) <= 1e-5 * np.abs(want).max(axis=1)).all()
