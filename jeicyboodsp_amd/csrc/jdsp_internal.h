@@ -96,16 +96,17 @@ struct MfccDev {
     const float *mel_fb;         // [512] rgdFilterBank as float (zero beyond n_bins)
     const int *mel_k;            // [512] rgdFiBins
     // lane-per-index form of the same filterbank (mfcc_x2_kernel): lane L sums the bins [seg[L].x, +seg[L].y)
-    // (at most 16, all with rgdFiBins value seg[L].z) with weights seg_w[t * 64 + L]; seg_ok = it fits 64 lanes
+    // (at most 16, all with rgdFiBins value seg[L].z); seg_wc[q * 64 + L] = {w, 1 - w of bin 2 q; w, 1 - w of bin 2 q + 1},
+    // both ZERO past the piece's last bin (eight dwordx4 loads per lane instead of thirty-two dwords, and each
+    // (w, 1 - w) an aligned register pair for the packed multiply-add); seg_ok = it fits 64 lanes
     const int4 *seg;
-    const float *seg_w;
-    const float *seg_c;          // 1 - seg_w inside a piece, 0 past its last bin
+    const float4 *seg_wc;
     int seg_ok;
     // per channel ch: lanes [x, x + y) hold pieces with index ch (their `hi` parts), lanes [z, z + w) pieces with index
     // ch + 1 (their `lo` parts); chan_ok = no channel needs more than four of either
     const int4 *chan_src;
     int chan_ok;
-    const double *dct;           // [n_chan][32]: sqrt(2/C) cos(PI i (k-0.5)/C)
+    const double *dct;           // [max(n_chan, 40)][32]: sqrt(2/C) cos(PI i (k-0.5)/C), zero past n_cep and past n_chan
     const double *lifter_w;      // [32]: 1 + L/2 sin(PI i / L)
 };
 

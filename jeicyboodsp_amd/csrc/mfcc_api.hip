@@ -59,7 +59,7 @@ int jdsp_mfcc_create(jdsp_ctx *ctx, const jdsp_mfcc_cfg *cfg, jdsp_mfcc **out)
     // ---- the same filterbank by channel index: every run of bins with one rgdFiBins value, cut into pieces of
     // at most 16 bins, one piece per lane (the index never decreases with the bin, :131-137) ----
     std::vector<int> seg(64 * 4, 0);
-    std::vector<float> seg_w(16 * 64, 0.f), seg_c(16 * 64, 0.f);
+    std::vector<float> seg_wc(2 * 16 * 64, 0.f);
     int seg_lanes = 0;
     bool seg_ok = true;
     for (int i = 0; i < NB && seg_ok;) {
@@ -70,8 +70,9 @@ int jdsp_mfcc_create(jdsp_ctx *ctx, const jdsp_mfcc_cfg *cfg, jdsp_mfcc **out)
             const int cnt = e - s0 < 16 ? e - s0 : 16;
             seg[4 * seg_lanes + 0] = s0; seg[4 * seg_lanes + 1] = cnt; seg[4 * seg_lanes + 2] = h->fi_bins[i];
             for (int t = 0; t < cnt; t++) {
-                seg_w[(size_t)t * 64 + seg_lanes] = (float)h->fbank[s0 + t];
-                seg_c[(size_t)t * 64 + seg_lanes] = (float)(1.0 - h->fbank[s0 + t]);             // (1 - rgdFilterBank[i]), :161,:165
+                const size_t at = ((size_t)(t >> 1) * 64 + seg_lanes) * 4 + 2 * (t & 1);           // MfccDev::seg_wc
+                seg_wc[at] = (float)h->fbank[s0 + t];
+                seg_wc[at + 1] = (float)(1.0 - h->fbank[s0 + t]);                                 // (1 - rgdFilterBank[i]), :161,:165
             }
             seg_lanes++;
         }
@@ -92,7 +93,7 @@ int jdsp_mfcc_create(jdsp_ctx *ctx, const jdsp_mfcc_cfg *cfg, jdsp_mfcc **out)
         chan_src[4 * ch + 2] = l0 < 0 ? 0 : l0; chan_src[4 * ch + 3] = lc;
     }
     // ---- DCT (:178-182) and lifter (:189) constants ----
-    std::vector<double> dct((size_t)C * 32, 0.0), lift(32, 0.0);
+    std::vector<double> dct((size_t)(C > 40 ? C : 40) * 32, 0.0), lift(32, 0.0);   // zero rows up to 40: mfcc_x2_kernel reads ten per lane group unguarded
     for (int i = 1; i <= c.n_cep; i++) {
         for (int k = 1; k <= C; k++) dct[(size_t)(k - 1) * 32 + (i - 1)] = sqrt(2.0 / C) * cos(PI * i * (k - 0.5) / (double)C);
         lift[i - 1] = (1 + 0.5 * c.lifter * sin(PI * i / c.lifter));
@@ -108,7 +109,7 @@ int jdsp_mfcc_create(jdsp_ctx *ctx, const jdsp_mfcc_cfg *cfg, jdsp_mfcc **out)
     const size_t o_win = 0, o_fb = o_win + sizeof(float2) * 512, o_k = o_fb + 512 * sizeof(float),
                  o_dct = o_k + 512 * sizeof(int), o_lift = o_dct + dct.size() * sizeof(double),
                  o_seg = o_lift + 32 * sizeof(double), o_segw = o_seg + seg.size() * sizeof(int),
-                 o_segc = o_segw + seg_w.size() * sizeof(float), o_chan = o_segc + seg_c.size() * sizeof(float),
+                 o_chan = o_segw + seg_wc.size() * sizeof(float),
                  total = o_chan + chan_src.size() * sizeof(int);
     std::vector<char> host(total, 0);
     memcpy(&host[o_win], window.data(), sizeof(float2) * 512);
@@ -117,8 +118,7 @@ int jdsp_mfcc_create(jdsp_ctx *ctx, const jdsp_mfcc_cfg *cfg, jdsp_mfcc **out)
     memcpy(&host[o_dct], dct.data(), dct.size() * sizeof(double));
     memcpy(&host[o_lift], lift.data(), 32 * sizeof(double));
     memcpy(&host[o_seg], seg.data(), seg.size() * sizeof(int));
-    memcpy(&host[o_segw], seg_w.data(), seg_w.size() * sizeof(float));
-    memcpy(&host[o_segc], seg_c.data(), seg_c.size() * sizeof(float));
+    memcpy(&host[o_segw], seg_wc.data(), seg_wc.size() * sizeof(float));
     memcpy(&host[o_chan], chan_src.data(), chan_src.size() * sizeof(int));
     hipError_t e = hipMalloc(&h->blob, total);
     if (e == hipSuccess) e = hipMemcpy(h->blob, host.data(), total, hipMemcpyHostToDevice);
@@ -135,8 +135,7 @@ int jdsp_mfcc_create(jdsp_ctx *ctx, const jdsp_mfcc_cfg *cfg, jdsp_mfcc **out)
     h->dev.mel_fb = (const float *)(b + o_fb);
     h->dev.mel_k = (const int *)(b + o_k);
     h->dev.seg = (const int4 *)(b + o_seg);
-    h->dev.seg_w = (const float *)(b + o_segw);
-    h->dev.seg_c = (const float *)(b + o_segc);
+    h->dev.seg_wc = (const float4 *)(b + o_segw);
     h->dev.seg_ok = seg_ok ? 1 : 0;
     h->dev.chan_src = (const int4 *)(b + o_chan);
     h->dev.chan_ok = chan_ok ? 1 : 0;

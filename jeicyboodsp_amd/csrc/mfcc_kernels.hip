@@ -187,6 +187,59 @@ __device__ __forceinline__ void mfcc_load_frame(const short *__restrict__ src, c
     }
 }
 
+// The same in two halves, so that a kernel can have every load of a wave -- both frames' samples, window, twiddles,
+// filterbank piece -- in flight before it waits for the first: mfcc_load_frame's `aligned?` branch sits between the
+// two frames' loads and the tables', which made three memory round trips in series of what can be one (ISA: frame a's
+// loads, s_waitcnt vmcnt(0), frame b's, vmcnt(0), tables), and its general path guards every halfword with a branch
+// and a wait of its own.  ALIGNED: the dword holding samples 2 lane + 128 r, +1 (the sample before them is the previous lane's).  Otherwise
+// three halfwords at positions clamped into [0, win_len): the window is zero wherever the clamp changes a position.
+template <bool ALIGNED> struct MfccRaw;
+template <> struct MfccRaw<true> { unsigned int cur[8]; };
+template <> struct MfccRaw<false> { int sm[8], s0[8], s1[8]; };
+
+__device__ __forceinline__ void mfcc_fetch(const short *__restrict__ src, const MfccDev &p, int lane, MfccRaw<true> &raw)
+{
+    const unsigned int *s32 = reinterpret_cast<const unsigned int *>(src) + lane;
+#pragma unroll
+    for (int r = 0; r < 8; r++) raw.cur[r] = s32[64 * r];
+}
+__device__ __forceinline__ void mfcc_fetch(const short *__restrict__ src, const MfccDev &p, int lane, MfccRaw<false> &raw)
+{
+    const int last = p.win_len - 1;
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const int i0 = 2 * lane + 128 * r;
+        raw.sm[r] = src[min(max(i0 - 1, 0), last)];
+        raw.s0[r] = src[min(i0, last)];
+        raw.s1[r] = src[min(i0 + 1, last)];
+    }
+}
+// x[i] = s[i] - preemph * s[i-1] for 1 <= i < win_len, x[0] = 0 (:208 starts at i = 1), times the window (zero beyond)
+__device__ __forceinline__ void mfcc_finish(const MfccRaw<true> &raw, const float2 (&w)[8], float preemph, int lane, float2 (&v)[8])
+{
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const float2 cur = unpack_i16x2(raw.cur[r]);
+        // the dword before this one: lane - 1's (wave_shr:1), lane 0's is lane 63's of the row before
+        const int up = __builtin_amdgcn_update_dpp(0, (int)raw.cur[r], 0x138, 0xf, 0xf, true);
+        const int wrap = r > 0 ? __builtin_amdgcn_readlane((int)raw.cur[r > 0 ? r - 1 : 0], 63) : 0;
+        const float sm = (float)((lane == 0 ? wrap : up) >> 16);
+        const float x0 = (r == 0 && lane == 0) ? 0.f : cur.x - preemph * sm;
+        const float x1 = cur.y - preemph * cur.x;
+        v[r] = make_float2(x0 * w[r].x, x1 * w[r].y);
+    }
+}
+__device__ __forceinline__ void mfcc_finish(const MfccRaw<false> &raw, const float2 (&w)[8], float preemph, int lane, float2 (&v)[8])
+{
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const float sm = (float)raw.sm[r], s0 = (float)raw.s0[r], s1 = (float)raw.s1[r];
+        const float x0 = (r == 0 && lane == 0) ? 0.f : s0 - preemph * sm;
+        const float x1 = s1 - preemph * s0;
+        v[r] = make_float2(x0 * w[r].x, x1 * w[r].y);
+    }
+}
+
 // |X[m]|, m = 128 j + 2 lane + e < 512, of the natural-order image `img` (:218-220)
 __device__ __forceinline__ void mfcc_magnitudes(const float2 *img, int lane, float2 wsp0, float2 wsp1, float2 (&amp)[4])
 {
@@ -284,31 +337,35 @@ __device__ __forceinline__ void mel_channel_sums(float (*pieces)[2][64], float (
 #ifndef JDSP_MFCC_X2_PAIRS
 #define JDSP_MFCC_X2_PAIRS 1
 #endif
+#ifndef JDSP_MFCC_MEL_BATCH
+#define JDSP_MFCC_MEL_BATCH 8      // bins per lane whose |X| reads are in flight together (16: 138 registers, three waves per SIMD)
+#endif
 #ifndef JDSP_MFCC_ABLATE
 #define JDSP_MFCC_ABLATE 0        // timing-only ablations of mfcc_x2_kernel's tail (tools/build_variant.sh): wrong results
 #endif
-__global__ __launch_bounds__(64) void mfcc_x2_kernel(const short *__restrict__ pcm, const long long *__restrict__ starts,
-                                                     long n_frames, MfccDev p, const float2 *__restrict__ table,
-                                                     double *__restrict__ feats)
+template <bool ALIGNED>
+__device__ __forceinline__ void mfcc_x2_body(const short *__restrict__ src_a, const short *__restrict__ src_b, long fa, long fb, bool two,
+                                             const MfccDev &p, const float2 *__restrict__ table, double *__restrict__ feats,
+                                             float2 (*lds)[kWaveLdsComplex], int lane)
 {
-    // 9,344 B per wave: the two transform scratches; |X| (544 floats each), the filterbank pieces and the channel
-    // logarithms live in the scratches' second halves (seventeen waves per CU instead of fourteen)
-    __shared__ __attribute__((aligned(16))) float2 lds[2][kWaveLdsComplex];
     float (*logmel)[64] = reinterpret_cast<float (*)[64]>(reinterpret_cast<float *>(lds[0]) + 640);       // [2][64]
     float (*pieces)[2][64] = reinterpret_cast<float (*)[2][64]>(reinterpret_cast<float *>(lds[1]) + 640); // [2][2][64]
-    const int lane = threadIdx.x;
-    const long per_xcd = (gridDim.x + 7) >> 3;
-    const long fa = ((long)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3)) * 2;
-    if (fa >= n_frames) return;
-    const bool two = fa + 1 < n_frames;
-    const long fb = two ? fa + 1 : fa;                               // odd tail: the second slot repeats the first
-    float2 va[8], vb[8];
-    mfcc_load_frame(pcm + (starts ? starts[fa] : (long long)p.hop * fa), p, lane, va);
-    mfcc_load_frame(pcm + (starts ? starts[fb] : (long long)p.hop * fb), p, lane, vb);
+    // every load the wave needs before its tail, requested in the order of use and none waited for yet (mfcc_fetch)
+    MfccRaw<ALIGNED> raw_a, raw_b;
+    mfcc_fetch(src_a, p, lane, raw_a);
+    mfcc_fetch(src_b, p, lane, raw_b);
+    float2 win[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) win[r] = p.window[lane + 64 * r];
     WaveTwiddles tw;
     load_wave_twiddles(tw, table, lane);
-    const float2 wsp0 = table[kStftSplit + 2 * lane];
-    const float2 wsp1 = table[kStftSplit + 2 * lane + 1];
+#if !JDSP_MFCC_X2_PAIRS
+    const float2 wsp0 = table[kStftSplit + 2 * lane], wsp1 = table[kStftSplit + 2 * lane + 1];
+#endif
+    float2 va[8], vb[8];
+    mfcc_finish(raw_a, win, p.preemph, lane, va);
+    mfcc_finish(raw_b, win, p.preemph, lane, vb);
+    // (requested once the samples' registers are free: they are not needed before the transforms are done)
     // this lane's piece of the filterbank: bins [sg.x, sg.x + sg.y) of channel index sg.z, weights sw[t] towards
     // channel sg.z - 1 and cw[t] = 1 - sw[t] towards channel sg.z; both are ZERO past the piece's last bin, so the
     // sixteen steps below need neither a branch nor a select (the branchy form compiled to 94 exec-mask regions
@@ -318,7 +375,11 @@ __global__ __launch_bounds__(64) void mfcc_x2_kernel(const short *__restrict__ p
     const int4 sg = p.seg[lane];
     float sw[16], cw[16];
 #pragma unroll
-    for (int t = 0; t < 16; t++) { sw[t] = p.seg_w[t * 64 + lane]; cw[t] = p.seg_c[t * 64 + lane]; }
+    for (int q = 0; q < 8; q++) {
+        const float4 a = p.seg_wc[q * 64 + lane];
+        sw[2 * q] = a.x; cw[2 * q] = a.y; sw[2 * q + 1] = a.z; cw[2 * q + 1] = a.w;
+    }
+    const double lw = p.lifter_w[lane & 31];
 
     wave_fft512_x2<false>(va, vb, lds[0], lds[1], lane, tw);
 #if JDSP_MFCC_X2_PAIRS
@@ -396,31 +457,33 @@ __global__ __launch_bounds__(64) void mfcc_x2_kernel(const short *__restrict__ p
     double dc[10];
 #pragma unroll
     for (int t = 0; t < 10; t++) {
-        const int k = cpart + cstep * t;
-        dc[t] = (ci < p.n_cep && k < p.n_chan) ? p.dct[k * 32 + ci] : 0.0;
-    }
+        dc[t] = p.dct[(cpart + cstep * t) * 32 + ci];                // unguarded (a guarded load is a branch and a wait of its
+    }                                                                // own): the table is zero past n_cep and n_chan, 40 rows
     // mel filterbank (:157-168), one channel index per lane: bin i of index k adds f_i m_i to channel k - 1 and
     // (1 - f_i) m_i to channel k, so a lane whose bins all share k sums both in registers and issues exactly two
     // LDS atomics.  (Walking 8 consecutive bins per lane and flushing whenever the index changed took ~18
     // atomic instructions per frame, ~32 LDS cycles each: the LDS pipe was busy 72 % of the kernel.)
     {
         float lo_a = 0.f, hi_a = 0.f, lo_b = 0.f, hi_b = 0.f;
-        float ma[16], mb[16];
 #pragma unroll
-        for (int t = 0; t < 16; t++) {                               // all thirty-two reads in flight together
-            const int bin = min(sg.x + t, 511);                      // past the piece: any finite value, its weights are 0
-            const int q = bin + (bin >> 4);
+        for (int h = 0; h < 16; h += JDSP_MFCC_MEL_BATCH) {          // JDSP_MFCC_MEL_BATCH x 2 reads in flight together
+            float ma[JDSP_MFCC_MEL_BATCH], mb[JDSP_MFCC_MEL_BATCH];
+#pragma unroll
+            for (int t = 0; t < JDSP_MFCC_MEL_BATCH; t++) {
+                const int bin = min(sg.x + h + t, 511);              // past the piece: any finite value, its weights are 0
+                const int q = bin + (bin >> 4);
 #if JDSP_MFCC_ABLATE & 1                                             /* timing-only: no filterbank reads */
-            ma[t] = (float)q; mb[t] = (float)(q + 1);
+                ma[t] = (float)q; mb[t] = (float)(q + 1);
 #else
-            ma[t] = mag_a[q];
-            mb[t] = mag_b[q];
+                ma[t] = mag_a[q];
+                mb[t] = mag_b[q];
 #endif
-        }
+            }
 #pragma unroll
-        for (int t = 0; t < 16; t++) {
-            lo_a = fmaf(sw[t], ma[t], lo_a); hi_a = fmaf(cw[t], ma[t], hi_a);   // :164 / :161,:165-166
-            lo_b = fmaf(sw[t], mb[t], lo_b); hi_b = fmaf(cw[t], mb[t], hi_b);
+            for (int t = 0; t < JDSP_MFCC_MEL_BATCH; t++) {
+                lo_a = fmaf(sw[h + t], ma[t], lo_a); hi_a = fmaf(cw[h + t], ma[t], hi_a);   // :164 / :161,:165-166
+                lo_b = fmaf(sw[h + t], mb[t], lo_b); hi_b = fmaf(cw[h + t], mb[t], hi_b);
+            }
         }
         if (p.chan_ok) {
             if (sg.y <= 0) { lo_a = hi_a = lo_b = hi_b = 0.f; }
@@ -464,11 +527,32 @@ __global__ __launch_bounds__(64) void mfcc_x2_kernel(const short *__restrict__ p
         if (!wide) { acc_a = sum_xor16_f64(acc_a); acc_b = sum_xor16_f64(acc_b); }
         acc_a = sum_xor32_f64(acc_a); acc_b = sum_xor32_f64(acc_b);
         if (lane < p.n_cep) {
-            const double lw = p.lifter_w[lane];
             feats[fa * p.n_cep + lane] = acc_a * lw;
             if (two) feats[fb * p.n_cep + lane] = acc_b * lw;
         }
     }
+}
+
+__global__ __launch_bounds__(64) void mfcc_x2_kernel(const short *__restrict__ pcm, const long long *__restrict__ starts,
+                                                     long n_frames, MfccDev p, const float2 *__restrict__ table,
+                                                     double *__restrict__ feats)
+{
+    // 9,344 B per wave: the two transform scratches; |X| (544 floats each), the filterbank pieces and the channel
+    // logarithms live in the scratches' second halves (seventeen waves per CU instead of fourteen)
+    __shared__ __attribute__((aligned(16))) float2 lds[2][kWaveLdsComplex];
+    const int lane = threadIdx.x;
+    const long per_xcd = (gridDim.x + 7) >> 3;
+    const long fa = ((long)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3)) * 2;
+    if (fa >= n_frames) return;
+    const bool two = fa + 1 < n_frames;
+    const long fb = two ? fa + 1 : fa;                               // odd tail: the second slot repeats the first
+    const short *src_a = pcm + (starts ? starts[fa] : (long long)p.hop * fa);
+    const short *src_b = pcm + (starts ? starts[fb] : (long long)p.hop * fb);
+    // full-length window and both frames 4-byte aligned: one dword per sample pair (wave-uniform)
+    if (p.win_len == 1024 && ((((uintptr_t)src_a) | ((uintptr_t)src_b)) & 3u) == 0)
+        mfcc_x2_body<true>(src_a, src_b, fa, fb, two, p, table, feats, lds, lane);
+    else
+        mfcc_x2_body<false>(src_a, src_b, fa, fb, two, p, table, feats, lds, lane);
 }
 
 // ---- persistent waves, spectrum in registers ------------------------------------------------------------------------
@@ -482,7 +566,10 @@ __device__ __forceinline__ void load_mel_piece(MelPiece &m, const MfccDev &p, in
 {
     m.sg = p.seg[lane];
 #pragma unroll
-    for (int t = 0; t < 16; t++) { m.sw[t] = p.seg_w[t * 64 + lane]; m.cw[t] = p.seg_c[t * 64 + lane]; }
+    for (int q = 0; q < 8; q++) {
+        const float4 a = p.seg_wc[q * 64 + lane];
+        m.sw[2 * q] = a.x; m.cw[2 * q] = a.y; m.sw[2 * q + 1] = a.z; m.cw[2 * q + 1] = a.w;
+    }
 }
 
 // |X| of two frames, bin i at mag[i + (i >> 4)] (see mfcc_x2_kernel) -> feats[fa], feats[fb]
