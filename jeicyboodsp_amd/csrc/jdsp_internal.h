@@ -96,11 +96,12 @@ struct MfccDev {
     const float *mel_fb;         // [512] rgdFilterBank as float (zero beyond n_bins)
     const int *mel_k;            // [512] rgdFiBins
     // lane-per-index form of the same filterbank (mfcc_x2_kernel): lane L sums the bins [seg[L].x, +seg[L].y)
-    // (at most 16, all with rgdFiBins value seg[L].z); seg_wc[q * 64 + L] = {w, 1 - w of bin 2 q; w, 1 - w of bin 2 q + 1},
+    // (at most piece_len, all with rgdFiBins value seg[L].z); seg_wc[q * 64 + L] = {w, 1 - w of bin 2 q; w, 1 - w of bin 2 q + 1},
     // both ZERO past the piece's last bin (eight dwordx4 loads per lane instead of thirty-two dwords, and each
     // (w, 1 - w) an aligned register pair for the packed multiply-add); seg_ok = it fits 64 lanes
     const int4 *seg;
     const float4 *seg_wc;
+    int piece_len;               // 8, 12 or 16: no piece is longer (the smallest for which the pieces fit 64 lanes)
     int seg_ok;
     // per channel ch: lanes [x, x + y) hold pieces with index ch (their `hi` parts), lanes [z, z + w) pieces with index
     // ch + 1 (their `lo` parts); chan_ok = no channel needs more than four of either

@@ -57,40 +57,50 @@ int jdsp_mfcc_create(jdsp_ctx *ctx, const jdsp_mfcc_cfg *cfg, jdsp_mfcc **out)
         mel_k[i] = i < NB ? h->fi_bins[i] : h->fi_bins[NB - 1];
     }
     // ---- the same filterbank by channel index: every run of bins with one rgdFiBins value, cut into pieces of
-    // at most 16 bins, one piece per lane (the index never decreases with the bin, :131-137) ----
-    std::vector<int> seg(64 * 4, 0);
-    std::vector<float> seg_wc(2 * 16 * 64, 0.f);
-    int seg_lanes = 0;
-    bool seg_ok = true;
-    for (int i = 0; i < NB && seg_ok;) {
-        int e = i;
-        while (e < NB && h->fi_bins[e] == h->fi_bins[i]) e++;
-        for (int s0 = i; s0 < e; s0 += 16) {
-            if (seg_lanes == 64) { seg_ok = false; break; }
-            const int cnt = e - s0 < 16 ? e - s0 : 16;
-            seg[4 * seg_lanes + 0] = s0; seg[4 * seg_lanes + 1] = cnt; seg[4 * seg_lanes + 2] = h->fi_bins[i];
-            for (int t = 0; t < cnt; t++) {
-                const size_t at = ((size_t)(t >> 1) * 64 + seg_lanes) * 4 + 2 * (t & 1);           // MfccDev::seg_wc
-                seg_wc[at] = (float)h->fbank[s0 + t];
-                seg_wc[at + 1] = (float)(1.0 - h->fbank[s0 + t]);                                 // (1 - rgdFilterBank[i]), :161,:165
+    // at most piece_len bins, one piece per lane (the index never decreases with the bin, :131-137).  piece_len is
+    // the smallest of 8, 12, 16 for which the pieces fit 64 lanes with at most four per channel: the kernels walk
+    // piece_len bins on every lane, so shorter pieces are less work (native 512 bins / 38 channels: 12; 256 / 40: 8) ----
+    std::vector<int> seg, chan_src;
+    std::vector<float> seg_wc;
+    int seg_lanes = 0, piece_len = 16;
+    bool seg_ok = true, chan_ok = true;
+    for (int want : {8, 12, 16}) {
+        piece_len = want;
+        seg.assign(64 * 4, 0);
+        seg_wc.assign(2 * 16 * 64, 0.f);
+        seg_lanes = 0;
+        seg_ok = true;
+        for (int i = 0; i < NB && seg_ok;) {
+            int e = i;
+            while (e < NB && h->fi_bins[e] == h->fi_bins[i]) e++;
+            for (int s0 = i; s0 < e; s0 += piece_len) {
+                if (seg_lanes == 64) { seg_ok = false; break; }
+                const int cnt = e - s0 < piece_len ? e - s0 : piece_len;
+                seg[4 * seg_lanes + 0] = s0; seg[4 * seg_lanes + 1] = cnt; seg[4 * seg_lanes + 2] = h->fi_bins[i];
+                for (int t = 0; t < cnt; t++) {
+                    const size_t at = ((size_t)(t >> 1) * 64 + seg_lanes) * 4 + 2 * (t & 1);       // MfccDev::seg_wc
+                    seg_wc[at] = (float)h->fbank[s0 + t];
+                    seg_wc[at + 1] = (float)(1.0 - h->fbank[s0 + t]);                             // (1 - rgdFilterBank[i]), :161,:165
+                }
+                seg_lanes++;
             }
-            seg_lanes++;
+            i = e;
         }
-        i = e;
-    }
-    // ---- per channel: which lanes' pieces feed it (mel_channel_sums) ----
-    std::vector<int> chan_src(64 * 4, 0);
-    bool chan_ok = seg_ok;
-    for (int ch = 0; ch < C && chan_ok; ch++) {
-        int h0 = -1, hc = 0, l0 = -1, lc = 0;
-        for (int L = 0; L < seg_lanes; L++) {
-            const int z = seg[4 * L + 2];
-            if (z == ch) { if (h0 < 0) h0 = L; hc++; }
-            if (z == ch + 1) { if (l0 < 0) l0 = L; lc++; }
+        // ---- per channel: which lanes' pieces feed it (mel_channel_sums) ----
+        chan_src.assign(64 * 4, 0);
+        chan_ok = seg_ok;
+        for (int ch = 0; ch < C && chan_ok; ch++) {
+            int h0 = -1, hc = 0, l0 = -1, lc = 0;
+            for (int L = 0; L < seg_lanes; L++) {
+                const int z = seg[4 * L + 2];
+                if (z == ch) { if (h0 < 0) h0 = L; hc++; }
+                if (z == ch + 1) { if (l0 < 0) l0 = L; lc++; }
+            }
+            if (hc > 4 || lc > 4) chan_ok = false;
+            chan_src[4 * ch + 0] = h0 < 0 ? 0 : h0; chan_src[4 * ch + 1] = hc;
+            chan_src[4 * ch + 2] = l0 < 0 ? 0 : l0; chan_src[4 * ch + 3] = lc;
         }
-        if (hc > 4 || lc > 4) chan_ok = false;
-        chan_src[4 * ch + 0] = h0 < 0 ? 0 : h0; chan_src[4 * ch + 1] = hc;
-        chan_src[4 * ch + 2] = l0 < 0 ? 0 : l0; chan_src[4 * ch + 3] = lc;
+        if (seg_ok && chan_ok) break;
     }
     // ---- DCT (:178-182) and lifter (:189) constants ----
     std::vector<double> dct((size_t)(C > 40 ? C : 40) * 32, 0.0), lift(32, 0.0);   // zero rows up to 40: mfcc_x2_kernel reads ten per lane group unguarded
@@ -136,6 +146,7 @@ int jdsp_mfcc_create(jdsp_ctx *ctx, const jdsp_mfcc_cfg *cfg, jdsp_mfcc **out)
     h->dev.mel_k = (const int *)(b + o_k);
     h->dev.seg = (const int4 *)(b + o_seg);
     h->dev.seg_wc = (const float4 *)(b + o_segw);
+    h->dev.piece_len = piece_len;
     h->dev.seg_ok = seg_ok ? 1 : 0;
     h->dev.chan_src = (const int4 *)(b + o_chan);
     h->dev.chan_ok = chan_ok ? 1 : 0;

@@ -6,6 +6,7 @@
 // n_fft = 512 (BASELINE config 4: 400-sample window, 512-FFT) runs on the same 1024-point
 // machinery: the 512-point spectrum of a frame is exactly the even bins of the 1024-point
 // spectrum of the same frame zero-padded.
+#include <type_traits>
 #include "frame_io.h"
 #include "jdsp_internal.h"
 
@@ -337,13 +338,121 @@ __device__ __forceinline__ void mel_channel_sums(float (*pieces)[2][64], float (
 #ifndef JDSP_MFCC_X2_PAIRS
 #define JDSP_MFCC_X2_PAIRS 1
 #endif
-#ifndef JDSP_MFCC_MEL_BATCH
-#define JDSP_MFCC_MEL_BATCH 8      // bins per lane whose |X| reads are in flight together (16: 138 registers, three waves per SIMD)
-#endif
 #ifndef JDSP_MFCC_ABLATE
 #define JDSP_MFCC_ABLATE 0        // timing-only ablations of mfcc_x2_kernel's tail (tools/build_variant.sh): wrong results
 #endif
-template <bool ALIGNED>
+// The tail both two-frame kernels share: |X| of two frames, bin i at mag[i + (i >> 4)] -> feats[fa], feats[fb].  sg/sw/cw:
+// this lane's filterbank piece (MfccDev::seg, seg_wc), dc: its ten DCT coefficients (rows cpart + cstep t of column ci,
+// unguarded loads from the zero-padded table), lw: its lifter weight -- all requested by the caller long before.
+template <int PL> struct MfccLaneTables { int4 sg; float sw[PL], cw[PL]; };
+template <int PL>
+__device__ __forceinline__ void mfcc_load_lane_tables(MfccLaneTables<PL> &m, const MfccDev &p, int lane)
+{
+    m.sg = p.seg[lane];
+#pragma unroll
+    for (int q = 0; q < PL / 2; q++) {
+        const float4 a = p.seg_wc[q * 64 + lane];
+        m.sw[2 * q] = a.x; m.cw[2 * q] = a.y; m.sw[2 * q + 1] = a.z; m.cw[2 * q + 1] = a.w;
+    }
+}
+__device__ __forceinline__ void mfcc_load_dct(double (&dc)[10], const MfccDev &p, int lane)
+{
+    const bool wide = p.n_cep > 16;                                  // see mfcc_kernel
+    const int ci = wide ? (lane & 31) : (lane & 15), cpart = wide ? (lane >> 5) : (lane >> 4), cstep = wide ? 2 : 4;
+#pragma unroll
+    for (int t = 0; t < 10; t++) dc[t] = p.dct[(cpart + cstep * t) * 32 + ci];   // (a guarded load is a branch and a wait of its own)
+}
+template <int PL>
+__device__ __forceinline__ void mfcc_tail_pre(const float *mag_a, const float *mag_b, float (*logmel)[64], float (*pieces)[2][64],
+                                              const MfccDev &p, int lane, const MfccLaneTables<PL> &mt, const double (&dc)[10],
+                                              double lw, long fa, long fb, bool two, double *__restrict__ feats)
+{
+    const bool wide = p.n_cep > 16;
+    const int ci = wide ? (lane & 31) : (lane & 15), cpart = wide ? (lane >> 5) : (lane >> 4), cstep = wide ? 2 : 4;
+    const int4 sg = mt.sg;
+    const float (&sw)[PL] = mt.sw;
+    const float (&cw)[PL] = mt.cw;
+    const int last_bin = p.n_bins - 1;
+    // mel filterbank (:157-168), one channel index per lane: bin i of index k adds f_i m_i to channel k - 1 and
+    // (1 - f_i) m_i to channel k, so a lane whose bins all share k sums both in registers and issues exactly two
+    // LDS atomics.  (Walking 8 consecutive bins per lane and flushing whenever the index changed took ~18
+    // atomic instructions per frame, ~32 LDS cycles each: the LDS pipe was busy 72 % of the kernel.)
+    {
+        float lo_a = 0.f, hi_a = 0.f, lo_b = 0.f, hi_b = 0.f;
+        // bins h .. h + N - 1 of the piece, 2 N reads in flight together (all 32 at once: 138 registers, three waves
+        // per SIMD).  PL (8, 12 or 16) = the longest piece, the smallest for which the pieces fit 64 lanes
+        // (mfcc_api.hip, MfccDev::piece_len): every lane walks PL bins, whatever its own piece's length.
+        auto batch = [&](auto H, auto N) {
+            constexpr int h = decltype(H)::value, n = decltype(N)::value;
+            float ma[n], mb[n];
+#pragma unroll
+            for (int t = 0; t < n; t++) {
+                const int bin = min(sg.x + h + t, last_bin);         // past the piece: any finite value, its weights are 0
+                const int q = bin + (bin >> 4);
+#if JDSP_MFCC_ABLATE & 1                                             /* timing-only: no filterbank reads */
+                ma[t] = (float)q; mb[t] = (float)(q + 1);
+#else
+                ma[t] = mag_a[q];
+                mb[t] = mag_b[q];
+#endif
+            }
+#pragma unroll
+            for (int t = 0; t < n; t++) {
+                lo_a = fmaf(sw[h + t], ma[t], lo_a); hi_a = fmaf(cw[h + t], ma[t], hi_a);   // :164 / :161,:165-166
+                lo_b = fmaf(sw[h + t], mb[t], lo_b); hi_b = fmaf(cw[h + t], mb[t], hi_b);
+            }
+        };
+        batch(std::integral_constant<int, 0>{}, std::integral_constant<int, 8>{});
+        if constexpr (PL > 8) batch(std::integral_constant<int, 8>{}, std::integral_constant<int, PL - 8>{});
+        if (p.chan_ok) {
+            if (sg.y <= 0) { lo_a = hi_a = lo_b = hi_b = 0.f; }
+            mel_channel_sums(pieces, logmel, p, lane, lo_a, hi_a, lo_b, hi_b);
+        } else {
+            if (sg.y > 0) {
+                if (sg.z >= 1) { atomicAdd(&logmel[0][sg.z - 1], lo_a); atomicAdd(&logmel[1][sg.z - 1], lo_b); }
+                if (sg.z < p.n_chan) { atomicAdd(&logmel[0][sg.z], hi_a); atomicAdd(&logmel[1][sg.z], hi_b); }
+            }
+            wave_lds_fence();
+            if (lane < p.n_chan) {
+                logmel[0][lane] = __logf(logmel[0][lane]);               // :171, as in mel_channel_sums
+                logmel[1][lane] = __logf(logmel[1][lane]);
+            }
+            wave_lds_fence();
+        }
+    }
+    // DCT-II (:178-182) and lifter (:189), both frames off one pass over the table
+    {
+        const int i = ci, part = cpart, step = cstep;
+        double acc_a = 0.0, acc_b = 0.0;
+        if (i < p.n_cep) {
+#pragma unroll
+            for (int t = 0; t < 10; t++) {
+                const int k = min(part + step * t, p.n_chan - 1);        // past the last channel: dc[t] is 0 -- but ln can be -inf
+                const float la = logmel[0][k], lb = logmel[1][k];
+                if (part + step * t < p.n_chan) {
+                    acc_a += dc[t] * (double)la;
+                    acc_b += dc[t] * (double)lb;
+                }
+            }
+#pragma unroll 4
+            for (int k = part + 10 * step; k < p.n_chan; k += step) {
+                const double c = p.dct[k * 32 + i];
+                acc_a += c * (double)logmel[0][k];
+                acc_b += c * (double)logmel[1][k];
+            }
+        }
+        // lane ^ 16 and lane ^ 32 partners by v_permlane16/32_swap (one VALU instruction per dword; a __shfl_xor is
+        // a ds_bpermute, 8.9 issue slots each on this chip: tools/valu_rate.hip)
+        if (!wide) { acc_a = sum_xor16_f64(acc_a); acc_b = sum_xor16_f64(acc_b); }
+        acc_a = sum_xor32_f64(acc_a); acc_b = sum_xor32_f64(acc_b);
+        if (lane < p.n_cep) {
+            feats[fa * p.n_cep + lane] = acc_a * lw;
+            if (two) feats[fb * p.n_cep + lane] = acc_b * lw;
+        }
+    }
+}
+
+template <bool ALIGNED, int PL>
 __device__ __forceinline__ void mfcc_x2_body(const short *__restrict__ src_a, const short *__restrict__ src_b, long fa, long fb, bool two,
                                              const MfccDev &p, const float2 *__restrict__ table, double *__restrict__ feats,
                                              float2 (*lds)[kWaveLdsComplex], int lane)
@@ -370,15 +479,8 @@ __device__ __forceinline__ void mfcc_x2_body(const short *__restrict__ src_a, co
     // channel sg.z - 1 and cw[t] = 1 - sw[t] towards channel sg.z; both are ZERO past the piece's last bin, so the
     // sixteen steps below need neither a branch nor a select (the branchy form compiled to 94 exec-mask regions
     // with a dependent LDS read and an s_waitcnt in each: the kernel spent 65 % of its wave cycles waiting)
-    const bool wide = p.n_cep > 16;                                  // see mfcc_kernel
-    const int ci = wide ? (lane & 31) : (lane & 15), cpart = wide ? (lane >> 5) : (lane >> 4), cstep = wide ? 2 : 4;
-    const int4 sg = p.seg[lane];
-    float sw[16], cw[16];
-#pragma unroll
-    for (int q = 0; q < 8; q++) {
-        const float4 a = p.seg_wc[q * 64 + lane];
-        sw[2 * q] = a.x; cw[2 * q] = a.y; sw[2 * q + 1] = a.z; cw[2 * q + 1] = a.w;
-    }
+    MfccLaneTables<PL> mt;
+    mfcc_load_lane_tables(mt, p, lane);
     const double lw = p.lifter_w[lane & 31];
 
     wave_fft512_x2<false>(va, vb, lds[0], lds[1], lane, tw);
@@ -455,84 +557,11 @@ __device__ __forceinline__ void mfcc_x2_body(const short *__restrict__ src_a, co
     // the DCT coefficients this lane will need (up to ten channels per quarter of the wave: 40 channels), requested
     // now -- the transforms' registers are free again -- so that they have arrived when the channel logarithms have
     double dc[10];
-#pragma unroll
-    for (int t = 0; t < 10; t++) {
-        dc[t] = p.dct[(cpart + cstep * t) * 32 + ci];                // unguarded (a guarded load is a branch and a wait of its
-    }                                                                // own): the table is zero past n_cep and n_chan, 40 rows
-    // mel filterbank (:157-168), one channel index per lane: bin i of index k adds f_i m_i to channel k - 1 and
-    // (1 - f_i) m_i to channel k, so a lane whose bins all share k sums both in registers and issues exactly two
-    // LDS atomics.  (Walking 8 consecutive bins per lane and flushing whenever the index changed took ~18
-    // atomic instructions per frame, ~32 LDS cycles each: the LDS pipe was busy 72 % of the kernel.)
-    {
-        float lo_a = 0.f, hi_a = 0.f, lo_b = 0.f, hi_b = 0.f;
-#pragma unroll
-        for (int h = 0; h < 16; h += JDSP_MFCC_MEL_BATCH) {          // JDSP_MFCC_MEL_BATCH x 2 reads in flight together
-            float ma[JDSP_MFCC_MEL_BATCH], mb[JDSP_MFCC_MEL_BATCH];
-#pragma unroll
-            for (int t = 0; t < JDSP_MFCC_MEL_BATCH; t++) {
-                const int bin = min(sg.x + h + t, 511);              // past the piece: any finite value, its weights are 0
-                const int q = bin + (bin >> 4);
-#if JDSP_MFCC_ABLATE & 1                                             /* timing-only: no filterbank reads */
-                ma[t] = (float)q; mb[t] = (float)(q + 1);
-#else
-                ma[t] = mag_a[q];
-                mb[t] = mag_b[q];
-#endif
-            }
-#pragma unroll
-            for (int t = 0; t < JDSP_MFCC_MEL_BATCH; t++) {
-                lo_a = fmaf(sw[h + t], ma[t], lo_a); hi_a = fmaf(cw[h + t], ma[t], hi_a);   // :164 / :161,:165-166
-                lo_b = fmaf(sw[h + t], mb[t], lo_b); hi_b = fmaf(cw[h + t], mb[t], hi_b);
-            }
-        }
-        if (p.chan_ok) {
-            if (sg.y <= 0) { lo_a = hi_a = lo_b = hi_b = 0.f; }
-            mel_channel_sums(pieces, logmel, p, lane, lo_a, hi_a, lo_b, hi_b);
-        } else {
-            if (sg.y > 0) {
-                if (sg.z >= 1) { atomicAdd(&logmel[0][sg.z - 1], lo_a); atomicAdd(&logmel[1][sg.z - 1], lo_b); }
-                if (sg.z < p.n_chan) { atomicAdd(&logmel[0][sg.z], hi_a); atomicAdd(&logmel[1][sg.z], hi_b); }
-            }
-            wave_lds_fence();
-            if (lane < p.n_chan) {
-                logmel[0][lane] = __logf(logmel[0][lane]);               // :171, as in mel_channel_sums
-                logmel[1][lane] = __logf(logmel[1][lane]);
-            }
-            wave_lds_fence();
-        }
-    }
-    // DCT-II (:178-182) and lifter (:189), both frames off one pass over the table
-    {
-        const int i = ci, part = cpart, step = cstep;
-        double acc_a = 0.0, acc_b = 0.0;
-        if (i < p.n_cep) {
-#pragma unroll
-            for (int t = 0; t < 10; t++) {
-                const int k = min(part + step * t, p.n_chan - 1);        // past the last channel: dc[t] is 0 -- but ln can be -inf
-                const float la = logmel[0][k], lb = logmel[1][k];
-                if (part + step * t < p.n_chan) {
-                    acc_a += dc[t] * (double)la;
-                    acc_b += dc[t] * (double)lb;
-                }
-            }
-#pragma unroll 4
-            for (int k = part + 10 * step; k < p.n_chan; k += step) {
-                const double c = p.dct[k * 32 + i];
-                acc_a += c * (double)logmel[0][k];
-                acc_b += c * (double)logmel[1][k];
-            }
-        }
-        // lane ^ 16 and lane ^ 32 partners by v_permlane16/32_swap (one VALU instruction per dword; a __shfl_xor is
-        // a ds_bpermute, 8.9 issue slots each on this chip: tools/valu_rate.hip)
-        if (!wide) { acc_a = sum_xor16_f64(acc_a); acc_b = sum_xor16_f64(acc_b); }
-        acc_a = sum_xor32_f64(acc_a); acc_b = sum_xor32_f64(acc_b);
-        if (lane < p.n_cep) {
-            feats[fa * p.n_cep + lane] = acc_a * lw;
-            if (two) feats[fb * p.n_cep + lane] = acc_b * lw;
-        }
-    }
+    mfcc_load_dct(dc, p, lane);
+    mfcc_tail_pre(mag_a, mag_b, logmel, pieces, p, lane, mt, dc, lw, fa, fb, two, feats);
 }
 
+template <int PL>
 __global__ __launch_bounds__(64) void mfcc_x2_kernel(const short *__restrict__ pcm, const long long *__restrict__ starts,
                                                      long n_frames, MfccDev p, const float2 *__restrict__ table,
                                                      double *__restrict__ feats)
@@ -550,9 +579,9 @@ __global__ __launch_bounds__(64) void mfcc_x2_kernel(const short *__restrict__ p
     const short *src_b = pcm + (starts ? starts[fb] : (long long)p.hop * fb);
     // full-length window and both frames 4-byte aligned: one dword per sample pair (wave-uniform)
     if (p.win_len == 1024 && ((((uintptr_t)src_a) | ((uintptr_t)src_b)) & 3u) == 0)
-        mfcc_x2_body<true>(src_a, src_b, fa, fb, two, p, table, feats, lds, lane);
+        mfcc_x2_body<true, PL>(src_a, src_b, fa, fb, two, p, table, feats, lds, lane);
     else
-        mfcc_x2_body<false>(src_a, src_b, fa, fb, two, p, table, feats, lds, lane);
+        mfcc_x2_body<false, PL>(src_a, src_b, fa, fb, two, p, table, feats, lds, lane);
 }
 
 // ---- persistent waves, spectrum in registers ------------------------------------------------------------------------
@@ -769,6 +798,10 @@ __global__ __launch_bounds__(64, JDSP_MFCC512_WAVES) void mfcc512_run_kernel(con
 #ifndef JDSP_MFCC512_ONE
 #define JDSP_MFCC512_ONE 1
 #endif
+#ifndef JDSP_MFCC512_EARLY_TABLES
+#define JDSP_MFCC512_EARLY_TABLES 0      // 1: 128 registers, four waves per SIMD, 50.5 us per 65,536 frames; 0: 82, five waves, 48.1 us
+#endif
+template <int PL>
 __global__ __launch_bounds__(64) void mfcc512_pair_kernel(const short *__restrict__ pcm, const long long *__restrict__ starts,
                                                           long n_frames, MfccDev p, const float2 *__restrict__ table,
                                                           double *__restrict__ feats, int *__restrict__ redo)
@@ -784,30 +817,43 @@ __global__ __launch_bounds__(64) void mfcc512_pair_kernel(const short *__restric
     const long fa = 2 * q;
     const bool two = fa + 1 < n_frames;
     const long fb = two ? fa + 1 : fa;
-    const int rows = (p.win_len + 63) >> 6;
+    // Every load of the wave is requested before the first is waited for, in the order of use: samples, window,
+    // twiddles, then (JDSP_MFCC512_EARLY_TABLES) the filterbank piece and the DCT column, which the tail needs only
+    // after the transform.  The samples are read UNGUARDED at positions clamped into the window -- the window table is
+    // zero from win_len on, so what a clamped position returns never counts.  (Guarded, each halfword was a branch
+    // with an s_waitcnt vmcnt(0) of its own: sixteen memory round trips in series per wave, hidden only by running
+    // seven waves per SIMD.)
     float sa[8], sb[8];
     {
-        const short *pa = pcm + (starts ? starts[fa] : (long long)p.hop * fa) + lane;
-        const short *pb = pcm + (starts ? starts[fb] : (long long)p.hop * fb) + lane;
+        const short *pa = pcm + (starts ? starts[fa] : (long long)p.hop * fa);
+        const short *pb = pcm + (starts ? starts[fb] : (long long)p.hop * fb);
+        const int last = p.win_len - 1;
 #pragma unroll
         for (int r = 0; r < 8; r++) {
-            const bool in = r < rows - 1 || (r == rows - 1 && lane + 64 * r < p.win_len);
-            sa[r] = in ? (float)pa[64 * r] : 0.f;
-            sb[r] = in ? (float)pb[64 * r] : 0.f;
+            const int i = min(lane + 64 * r, last);
+            sa[r] = (float)pa[i];
+            sb[r] = (float)pb[i];
         }
     }
-    float ma[4], mb[4];
-    {
-        WaveTwiddles tw;
-        load_wave_twiddles(tw, table, lane);
-        float win[8];
+    float win[8];
 #pragma unroll
-        for (int r = 0; r < 8; r++) win[r] = reinterpret_cast<const float *>(p.window)[lane + 64 * r];
-        if (mfcc512_pair_mags(sa, sb, p.preemph, win, tw, lds, lane, ma, mb) && lane == 0)
-            redo[1 + atomicAdd(redo, 1)] = (int)q;
-    }
-    MelPiece mp;
-    load_mel_piece(mp, p, lane);
+    for (int r = 0; r < 8; r++) win[r] = reinterpret_cast<const float *>(p.window)[lane + 64 * r];
+    WaveTwiddles tw;
+    load_wave_twiddles(tw, table, lane);
+    MfccLaneTables<PL> mt;
+    double dc[10];
+#if JDSP_MFCC512_EARLY_TABLES
+    mfcc_load_lane_tables(mt, p, lane);
+    mfcc_load_dct(dc, p, lane);
+#endif
+    const double lw = p.lifter_w[lane & 31];
+    float ma[4], mb[4];
+    if (mfcc512_pair_mags(sa, sb, p.preemph, win, tw, lds, lane, ma, mb) && lane == 0)
+        redo[1 + atomicAdd(redo, 1)] = (int)q;
+#if !JDSP_MFCC512_EARLY_TABLES
+    mfcc_load_lane_tables(mt, p, lane);
+    mfcc_load_dct(dc, p, lane);
+#endif
     float *mag_a = reinterpret_cast<float *>(lds), *mag_b = mag_a + 320;
 #pragma unroll
     for (int d = 0; d < 4; d++) {
@@ -815,10 +861,10 @@ __global__ __launch_bounds__(64) void mfcc512_pair_kernel(const short *__restric
         mag_a[qk] = ma[d];
         mag_b[qk] = mb[d];
     }
-    logmel[0][lane] = 0.f;
+    logmel[0][lane] = 0.f;                                           // (the atomics of the !chan_ok form add to them)
     logmel[1][lane] = 0.f;
     wave_lds_fence();
-    mfcc_tail_x2(mag_a, mag_b, logmel, pieces, p, lane, mp, fa, fb, two, feats);
+    mfcc_tail_pre(mag_a, mag_b, logmel, pieces, p, lane, mt, dc, lw, fa, fb, two, feats);
 }
 
 // (Tried for n_fft = 1024 too -- two frames per iteration through wave_fft512_x2, pair-owned |X|, tables in registers:
@@ -841,8 +887,10 @@ int launch_mfcc(hipStream_t s, const short *pcm, const long long *starts, long n
         const long n_pairs = (n_frames + 1) / 2;
         if (hipMemsetAsync(redo, 0, sizeof(int), s) != hipSuccess) return -1;
         if (JDSP_MFCC512_ONE) {
-            hipLaunchKernelGGL(mfcc512_pair_kernel, dim3((unsigned)((n_pairs + 7) / 8 * 8)), dim3(64), 0, s, pcm, starts, n_frames, p,
-                               table, feats, redo);
+            const dim3 grid((unsigned)((n_pairs + 7) / 8 * 8));
+            if (p.piece_len <= 8) hipLaunchKernelGGL(mfcc512_pair_kernel<8>, grid, dim3(64), 0, s, pcm, starts, n_frames, p, table, feats, redo);
+            else if (p.piece_len <= 12) hipLaunchKernelGGL(mfcc512_pair_kernel<12>, grid, dim3(64), 0, s, pcm, starts, n_frames, p, table, feats, redo);
+            else hipLaunchKernelGGL(mfcc512_pair_kernel<16>, grid, dim3(64), 0, s, pcm, starts, n_frames, p, table, feats, redo);
         } else {
             const long slots = 1024L * JDSP_MFCC512_WAVES;          // resident waves of a 256-CU part
             const long grid = n_pairs < slots ? n_pairs : slots;
@@ -851,7 +899,9 @@ int launch_mfcc(hipStream_t s, const short *pcm, const long long *starts, long n
         hipLaunchKernelGGL(mfcc_kernel, dim3(1024), dim3(64), 0, s, pcm, starts, n_frames, p, table, feats, (const int *)redo);
     } else if (JDSP_MFCC_X2 && p.seg_ok) {
         const long grid = ((n_frames + 1) / 2 + 7) / 8 * 8;
-        hipLaunchKernelGGL(mfcc_x2_kernel, dim3((unsigned)grid), dim3(64), 0, s, pcm, starts, n_frames, p, table, feats);
+        if (p.piece_len <= 8) hipLaunchKernelGGL(mfcc_x2_kernel<8>, dim3((unsigned)grid), dim3(64), 0, s, pcm, starts, n_frames, p, table, feats);
+        else if (p.piece_len <= 12) hipLaunchKernelGGL(mfcc_x2_kernel<12>, dim3((unsigned)grid), dim3(64), 0, s, pcm, starts, n_frames, p, table, feats);
+        else hipLaunchKernelGGL(mfcc_x2_kernel<16>, dim3((unsigned)grid), dim3(64), 0, s, pcm, starts, n_frames, p, table, feats);
     } else {                              // filterbanks that do not fit one piece per lane (many narrow channels)
         const long grid = (n_frames + 7) / 8 * 8;
         hipLaunchKernelGGL(mfcc_kernel, dim3((unsigned)grid), dim3(64), 0, s, pcm, starts, n_frames, p, table, feats,
