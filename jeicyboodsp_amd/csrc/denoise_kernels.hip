@@ -847,6 +847,16 @@ __device__ __forceinline__ const float *noise_row(const float *__restrict__ rows
     if (v < 0) v = 0;
     return rows + (size_t)v * 1024;
 }
+// The same with *sh.ver_row_off read once by the caller (a persistent wave's loop: read inside it, that load is a
+// vector load with an s_waitcnt vmcnt(0) behind it -- which also waits for the block prefetch issued just before)
+__device__ __forceinline__ const float *noise_row_at(const float *__restrict__ rows, const int *__restrict__ ver_base,
+                                                     const unsigned long long *__restrict__ snap_mask, long j,
+                                                     long ver_block_off, int row_off)
+{
+    int v = version_of(ver_base, snap_mask, j + ver_block_off) - row_off;
+    if (v < 0) v = 0;
+    return rows + (size_t)v * 1024;
+}
 
 template <int MODE, int K>
 __global__ __launch_bounds__(64, JDSP_DENOISE_MINWAVES) void denoise_kernel(
@@ -980,6 +990,7 @@ __global__ __launch_bounds__(64, JDSP_DENOISE_RESIDENT) void denoise_run_kernel(
     unsigned int raw[8], nxt[4];
     float2 tail[4], y[8];
     const float *cur_row = nullptr;
+    const int row_off = sh.ver_row_off ? *sh.ver_row_off : 0;          // once: see noise_row_at
     load_block_pairs(pcm, n_blocks, st_in, j0 - 2, lane, nxt);
 #pragma unroll
     for (int r = 0; r < 4; r++) raw[r] = nxt[r];
@@ -996,7 +1007,7 @@ __global__ __launch_bounds__(64, JDSP_DENOISE_RESIDENT) void denoise_run_kernel(
 #pragma unroll
         for (int d = 0; d < 4; d++) tail[d] = make_float2(0.f, 0.f);
     } else {
-        cur_row = noise_row(noise_rows, ver_base, snap_mask, j0 - 1, sh);
+        cur_row = noise_row_at(noise_rows, ver_base, snap_mask, j0 - 1, sh.ver_block_off, row_off);
         JDSP_RUN_LOAD_NOISE(cur_row);
         JDSP_RUN_FRAME();                                          // halo frame
 #pragma unroll
@@ -1029,7 +1040,7 @@ __global__ __launch_bounds__(64, JDSP_DENOISE_RESIDENT) void denoise_run_kernel(
 #pragma unroll
             for (int d = 0; d < 8; d++) y[d] = make_float2(0.f, 0.f);
         } else {
-            const float *row = noise_row(noise_rows, ver_base, snap_mask, j, sh);
+            const float *row = noise_row_at(noise_rows, ver_base, snap_mask, j, sh.ver_block_off, row_off);
             if (row != cur_row) {                                // wave-uniform: a new estimate was latched
                 cur_row = row;
                 JDSP_RUN_LOAD_NOISE(row);
@@ -1595,11 +1606,24 @@ __global__ __launch_bounds__(64, JDSP_DENOISE512_WAVES(MODE)) void denoise512_ru
     for (int r = 0; r < 8; r++) win[r] = win512[lane + 64 * r];
 
     // blocks ja - 1, ja, ja + 1 of the current pair (ja, ja + 1), samples lane + 64 t of each
-    float xk[3][4], nx[2][4];
+    // (the next pair's blocks stay raw halfwords until the rotation at the bottom of the loop: a conversion next to the
+    // loads sits inside their wave-uniform branch, and the s_waitcnt with it -- the "prefetch" then costs a full memory
+    // round trip per pair before the transforms start)
+    float xk[3][4];
+    int nx[2][4];
+    if (j0 >= 2 && j0 + 1 <= n_blocks) {                      // all three inside this call's buffer (wave-uniform): twelve
+        const short *src = pcm + (j0 - 2) * 256 + lane;       // loads in flight together; guarded, each waits for itself
 #pragma unroll
-    for (int b = 0; b < 3; b++)
+        for (int b = 0; b < 3; b++)
 #pragma unroll
-        for (int t = 0; t < 4; t++) xk[b][t] = dn512_sample(pcm, n_samples, st_in, (j0 - 2 + b) * 256 + lane + 64 * t);
+            for (int t = 0; t < 4; t++) xk[b][t] = (float)src[256 * b + 64 * t];
+    } else {
+#pragma unroll
+        for (int b = 0; b < 3; b++)
+#pragma unroll
+            for (int t = 0; t < 4; t++) xk[b][t] = dn512_sample(pcm, n_samples, st_in, (j0 - 2 + b) * 256 + lane + 64 * t);
+    }
+    const int row_off = sh.ver_row_off ? *sh.ver_row_off : 0;
     float na[5], nb[5], tail[4];
     const float *row_a = nullptr, *row_b = nullptr;
     const long first_emit = sh.emit_from;
@@ -1619,17 +1643,17 @@ __global__ __launch_bounds__(64, JDSP_DENOISE512_WAVES(MODE)) void denoise512_ru
             if (ja + 2 >= 0 && ja + 4 <= n_blocks) {            // both inside this call's buffer (wave-uniform)
                 const short *src = pcm + (ja + 2) * 256 + lane;
 #pragma unroll
-                for (int t = 0; t < 4; t++) { nx[0][t] = (float)src[64 * t]; nx[1][t] = (float)src[256 + 64 * t]; }
+                for (int t = 0; t < 4; t++) { nx[0][t] = src[64 * t]; nx[1][t] = src[256 + 64 * t]; }
             } else {
 #pragma unroll
                 for (int b = 0; b < 2; b++)
 #pragma unroll
-                    for (int t = 0; t < 4; t++) nx[b][t] = dn512_sample(pcm, n_samples, st_in, (ja + 2 + b) * 256 + lane + 64 * t);
+                    for (int t = 0; t < 4; t++) nx[b][t] = (int)dn512_sample(pcm, n_samples, st_in, (ja + 2 + b) * 256 + lane + 64 * t);
             }
         }
         {
-            const float *ra = noise_row(noise_rows, ver_base, snap_mask, ja >= 0 ? ja : 0, sh);
-            const float *rb = noise_row(noise_rows, ver_base, snap_mask, jb < n_blocks ? jb : n_blocks - 1, sh);
+            const float *ra = noise_row_at(noise_rows, ver_base, snap_mask, ja >= 0 ? ja : 0, sh.ver_block_off, row_off);
+            const float *rb = noise_row_at(noise_rows, ver_base, snap_mask, jb < n_blocks ? jb : n_blocks - 1, sh.ver_block_off, row_off);
             if (ra != row_a) { row_a = ra; load_noise512_regs<MODE>(na, ra, lane); }     // wave-uniform: a new estimate was latched
             if (rb != row_b) { row_b = rb; load_noise512_regs<MODE>(nb, rb, lane); }
         }
@@ -1730,8 +1754,8 @@ __global__ __launch_bounds__(64, JDSP_DENOISE512_WAVES(MODE)) void denoise512_ru
         for (int d = 0; d < 4; d++) {
             tail[d] = tail_b[d];
             xk[0][d] = xk[2][d];
-            xk[1][d] = nx[0][d];
-            xk[2][d] = nx[1][d];
+            xk[1][d] = (float)nx[0][d];
+            xk[2][d] = (float)nx[1][d];
         }
         halo = false;
     }
