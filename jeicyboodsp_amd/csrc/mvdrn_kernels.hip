@@ -571,7 +571,13 @@ __global__ __launch_bounds__(64) void mvdrn512_event_spectra_kernel(const short 
 
 // One wave = two consecutive blocks (j, j+1): per block ceil(n_mics / 2) forward transforms, Y_t[k] = sum_m conj(w_k[m]) X_m[k]
 // for k <= 256; then ONE inverse transform of Y_0 + j Y_1 (both Hermitian) gives the two output frames.
-__global__ __launch_bounds__(64) void mvdrn512_apply_kernel(const short *__restrict__ pcm, long chan_stride, int n_mics,
+#ifndef JDSP_MVN512_EARLY_WEIGHTS
+#define JDSP_MVN512_EARLY_WEIGHTS 1
+#endif
+#ifndef JDSP_MVN512_APPLY_WAVES
+#define JDSP_MVN512_APPLY_WAVES 3
+#endif
+__global__ __launch_bounds__(64, JDSP_MVN512_APPLY_WAVES) void mvdrn512_apply_kernel(const short *__restrict__ pcm, long chan_stride, int n_mics,
                                                             long n_blocks, long calls_before,
                                                             const short *__restrict__ prev_in, short *__restrict__ prev_out,
                                                             const int *__restrict__ ver_base,
@@ -598,25 +604,27 @@ __global__ __launch_bounds__(64) void mvdrn512_apply_kernel(const short *__restr
         if (j >= n_blocks) break;
         const bool have_prev = calls_before + j > 0;
         const float2 *W = weights + (size_t)version_of(ver_base, snap_mask, j) * kMvn512Bins * 8;
-        for (int m0 = 0; m0 < n_mics; m0 += 2) {
-            const int m1 = m0 + 1;
-            const short *ca = pcm + (size_t)m0 * chan_stride, *cb = pcm + (size_t)(m1 < n_mics ? m1 : m0) * chan_stride;
-            const short *pa = prev_in + (size_t)m0 * 512, *pb = prev_in + (size_t)(m1 < n_mics ? m1 : m0) * 512;
-            float xa[8], xb[8];
+        // The frame's samples of microphones m0, m0 + 1 as raw halfwords.  They are requested one microphone pair ahead
+        // and converted only where they are used: converted next to the loads, the s_waitcnt sits there too, and the
+        // guarded weight loads below each waited for themselves -- about six memory round trips in series per pair and
+        // 48 per wave, which was most of this kernel's time (ISA before: 30 s_waitcnt vmcnt(0) in this loop).
+        auto fetch = [&](int m0, int (&ra)[8], int (&rb)[8]) {
+            const int m1 = m0 + 1 < n_mics ? m0 + 1 : m0;
+            const short *ca = pcm + (size_t)m0 * chan_stride, *cb = pcm + (size_t)m1 * chan_stride;
             if (j >= 1) {
                 // both blocks inside this call's buffer (wave-uniform): frame position pos is stream sample
                 // (j - 1) 256 + pos, one further from 255 on (the previous block's last sample is not in the frame),
-                // and 511 is the zero -- one load and one select per sample, no per-lane branches
+                // and 511 is the zero -- one load per sample, no per-lane branches
                 const short *fa = ca + (j - 1) * 256 + lane, *fb = cb + (j - 1) * 256 + lane;
 #pragma unroll
                 for (int r = 0; r < 8; r++) {
                     const int pos = lane + 64 * r;
                     const int off = 64 * r + (pos >= 255 ? 1 : 0) - (pos == 511 ? 1 : 0);      // (keeps the last lane in bounds)
-                    const float a = (float)fa[off], b = (float)fb[off];
-                    xa[r] = pos < 511 ? a : 0.f;
-                    xb[r] = (pos < 511 && m1 < n_mics) ? b : 0.f;
+                    ra[r] = fa[off];
+                    rb[r] = fb[off];
                 }
             } else {
+                const short *pa = prev_in + (size_t)m0 * 512, *pb = prev_in + (size_t)m1 * 512;
 #pragma unroll
                 for (int r = 0; r < 8; r++) {
                     const int pos = lane + 64 * r;        // frame position: < 255 previous block, 255..510 this block, 511 zero
@@ -627,30 +635,60 @@ __global__ __launch_bounds__(64) void mvdrn512_apply_kernel(const short *__restr
                         a = (float)ca[j * 256 + pos - 255];
                         b = (float)cb[j * 256 + pos - 255];
                     }
-                    xa[r] = a;
-                    xb[r] = m1 < n_mics ? b : 0.f;
+                    ra[r] = (int)a;
+                    rb[r] = (int)b;
                 }
             }
-            float2 A[5], B[5];
-            mvn512_pair_spectra(xa, xb, tw, lds, lane, A, B);
-            const float2 *Wa = W + (size_t)m0 * kMvn512Bins, *Wb = W + (size_t)(m1 < n_mics ? m1 : m0) * kMvn512Bins;
+        };
+        int ra[8], rb[8];
+        fetch(0, ra, rb);
+        for (int m0 = 0; m0 < n_mics; m0 += 2) {
+            const int m1 = m0 + 1;
+            const bool two = m1 < n_mics;
+            // this pair's weights, unguarded (a lone last microphone reads its own row twice: its B spectrum is zero)
+            const float2 *Wa = W + (size_t)m0 * kMvn512Bins, *Wb = W + (size_t)(two ? m1 : m0) * kMvn512Bins;
+            float2 wa[5], wb[5];
+#if JDSP_MVN512_EARLY_WEIGHTS
 #pragma unroll
             for (int q = 0; q < 5; q++) {
                 const int k = q < 4 ? lane + 64 * q : 256;
-                const float2 wa = Wa[k];
-                Y[t][q].x += wa.x * A[q].x + wa.y * A[q].y;                 // conj(w) X
-                Y[t][q].y += wa.x * A[q].y - wa.y * A[q].x;
-                if (m1 < n_mics) {
-                    const float2 wb = Wb[k];
-                    Y[t][q].x += wb.x * B[q].x + wb.y * B[q].y;
-                    Y[t][q].y += wb.x * B[q].y - wb.y * B[q].x;
+                wa[q] = Wa[k];
+                wb[q] = Wb[k];
+            }
+#endif
+            float xa[8], xb[8];
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const int pos = lane + 64 * r;
+                xa[r] = pos < 511 ? (float)ra[r] : 0.f;
+                xb[r] = (pos < 511 && two) ? (float)rb[r] : 0.f;
+            }
+            if (m0 + 2 < n_mics) fetch(m0 + 2, ra, rb);
+            float2 A[5], B[5];
+            mvn512_pair_spectra(xa, xb, tw, lds, lane, A, B);
+#if !JDSP_MVN512_EARLY_WEIGHTS
+#pragma unroll
+            for (int q = 0; q < 5; q++) {
+                const int k = q < 4 ? lane + 64 * q : 256;
+                wa[q] = Wa[k];
+                wb[q] = Wb[k];
+            }
+#endif
+#pragma unroll
+            for (int q = 0; q < 5; q++) {
+                Y[t][q].x += wa[q].x * A[q].x + wa[q].y * A[q].y;           // conj(w) X
+                Y[t][q].y += wa[q].x * A[q].y - wa[q].y * A[q].x;
+                if (two) {                                                   // (wave-uniform)
+                    Y[t][q].x += wb[q].x * B[q].x + wb[q].y * B[q].y;
+                    Y[t][q].y += wb[q].x * B[q].y - wb[q].y * B[q].x;
                 }
             }
             if (j == n_blocks - 1) {                                         // the previous block of the next call
+                const short *ca = pcm + (size_t)m0 * chan_stride, *cb = pcm + (size_t)(two ? m1 : m0) * chan_stride;
 #pragma unroll
                 for (int d = 0; d < 4; d++) {
                     prev_out[(size_t)m0 * 512 + lane + 64 * d] = ca[j * 256 + lane + 64 * d];
-                    if (m1 < n_mics) prev_out[(size_t)m1 * 512 + lane + 64 * d] = cb[j * 256 + lane + 64 * d];
+                    if (two) prev_out[(size_t)m1 * 512 + lane + 64 * d] = cb[j * 256 + lane + 64 * d];
                 }
             }
         }
