@@ -117,6 +117,10 @@ def test_silent_frame_gives_minus_inf_like_reference(eng, oracle):
     (dict(win_len=512, hop=256, n_fft=512, n_chan=64, n_cep=13, half_rate=8000.0), 256),   # the one-frame kernel runs
     (dict(n_chan=12, n_cep=12), 512),                                   # wide channels: several 16-bin pieces each
     (dict(n_chan=1, n_cep=1), 512),
+    (dict(n_chan=38, n_cep=20), 512),                                   # more than 16 cepstra: two lane groups, DCT tail loop
+    (dict(n_chan=26, n_cep=13), 512),                                   # pieces of 16 bins (38 channels: 12)
+    (dict(win_len=400, hop=160, n_fft=512, n_chan=20, n_cep=13, half_rate=8000.0), 256),   # pair kernel, pieces longer than 8
+    (dict(win_len=1000, hop=250, n_chan=38, n_cep=12), 512),            # window shorter than the transform: clamped loads
 ])
 def test_filterbank_shapes_and_odd_frame_counts(eng, oracle, kw, n_bins):
     """Both MFCC kernels (two frames per wave with one filterbank piece per lane; one frame per wave when the
