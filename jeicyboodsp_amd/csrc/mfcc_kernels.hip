@@ -585,10 +585,10 @@ __global__ __launch_bounds__(64) void mfcc_x2_kernel(const short *__restrict__ p
 }
 
 // ---- persistent waves, spectrum in registers ------------------------------------------------------------------------
-// mfcc_x2_kernel reloads ~64 table values per wave (twiddles, window, filterbank pieces) for its two frames and spends
-// 44 % of its wave cycles in s_waitcnt; the kernels below keep the tables in registers over a grid-stride loop of frame
-// pairs, request the next pair's samples before this pair's arithmetic, take |X| from registers (frame_io.h: mirror
-// operands by pair_fetch_lds, no natural-order image) and share mfcc_x2_kernel's filterbank / ln / DCT / lifter tail.
+// (Round 2, when mfcc_x2_kernel still spent 44 % of its wave cycles in s_waitcnt:) the kernels below keep the tables in
+// registers over a grid-stride loop of frame pairs, request the next pair's samples before this pair's arithmetic, take
+// |X| from registers (frame_io.h: mirror operands by pair_fetch_lds, no natural-order image) and share a filterbank /
+// ln / DCT / lifter tail.  The persistent form stays selectable (JDSP_MFCC512_ONE = 0); production is the pair kernel.
 struct MelPiece { int4 sg; float sw[16], cw[16]; };
 
 __device__ __forceinline__ void load_mel_piece(MelPiece &m, const MfccDev &p, int lane)
@@ -791,9 +791,10 @@ __global__ __launch_bounds__(64, JDSP_MFCC512_WAVES) void mfcc512_run_kernel(con
 }
 
 // The same pair of frames, ONE pair per wave: nothing is kept between pairs, so the tables are loaded where they are
-// used and die there -- 62 registers instead of 168, eight waves per SIMD instead of three, against ~60 table loads
-// per pair.  This kernel waits on ten LDS round trips per pair and occupancy is what hides them: 53 us per 65,536
-// frames against the persistent kernel's 78, the 10,000-utterance batch 2.7 ms against 4.5 (profiles/r02_mfcc512_run.txt).
+// used and die there -- 72 registers instead of 168, seven waves per SIMD instead of three.  Round 2: 53 us per
+// 65,536 frames against the persistent kernel's 78 (profiles/r02_mfcc512_run.txt); round 3, with every load of the
+// wave unguarded and in flight together and the pieces cut to the filterbank: 43 us, the 10,000-utterance batch 2.05 ms
+// (profiles/r03_guarded_loads.txt).
 // JDSP_MFCC512_ONE = 0 selects the persistent kernel.
 #ifndef JDSP_MFCC512_ONE
 #define JDSP_MFCC512_ONE 1
