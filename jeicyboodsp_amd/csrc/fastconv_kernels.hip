@@ -352,10 +352,10 @@ __global__ __launch_bounds__(64, JDSP_CONV1024_MINWAVES) void fastconv1024_pairs
             float2 *lds_b = lds + (NF == 2 ? kWaveLdsComplex : 0);
             // both ears' mirror halves go to their owners in one round trip
 #pragma unroll
-            for (int d = 0; d < 4; d++) { lds[512 - lane - 64 * d] = ret[0][d]; lds_b[512 - lane - 64 * d] = ret[1][d]; }
+            for (int d = 0; d < 4; d++) { xchg_st(lds, 512 - lane - 64 * d, ret[0][d]); xchg_st(lds_b, 512 - lane - 64 * d, ret[1][d]); }
             wave_lds_fence();
 #pragma unroll
-            for (int d = 5; d < 8; d++) { yy[0][d] = lds[lane + 64 * d]; yy[NF - 1][d] = lds_b[lane + 64 * d]; }
+            for (int d = 5; d < 8; d++) { yy[0][d] = xchg_ld(lds, lane + 64 * d); yy[NF - 1][d] = xchg_ld(lds_b, lane + 64 * d); }
             wave_lds_fence();
             wave_fft512_x2_staggered<true>(yy[0], yy[NF - 1], lds, lds_b, lane, tw);
         }

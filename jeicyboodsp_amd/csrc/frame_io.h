@@ -72,7 +72,7 @@ __device__ __forceinline__ float2 presplit_inv(float2 ylo, float2 yhi, float2 ws
 __device__ __forceinline__ void store_natural_image(float2 *img, int lane, const float2 (&v)[8])
 {
 #pragma unroll
-    for (int d = 0; d < 8; d++) img[lane + 64 * d] = v[d];
+    for (int d = 0; d < 8; d++) xchg_st(img, lane + 64 * d, v[d]);
     if (lane == 0) img[512] = v[0];
 }
 // Z[512 - m] and Z[511 - m]: two ADJACENT elements, consecutive across lanes -> one conflict-free
@@ -121,7 +121,7 @@ __device__ __forceinline__ void mirror_fetch_lds(const float2 (&v)[8], float2 *i
     store_natural_image(img, lane, v);
     wave_lds_fence();
 #pragma unroll
-    for (int d = 0; d < 8; d++) zr[d] = img[512 - lane - 64 * d];
+    for (int d = 0; d < 8; d++) zr[d] = xchg_ld(img, 512 - lane - 64 * d);
     wave_lds_fence();
 }
 
@@ -172,11 +172,11 @@ __device__ __forceinline__ void load_pair_twiddles(PairTwiddles &t, const float2
 __device__ __forceinline__ void pair_fetch_lds(const float2 (&v)[8], float2 *img, int lane, float2 (&zr)[5])
 {
 #pragma unroll
-    for (int d = 3; d < 8; d++) img[lane + 64 * d] = v[d];
+    for (int d = 3; d < 8; d++) xchg_st(img, lane + 64 * d, v[d]);
     if (lane == 0) img[512] = v[0];
     wave_lds_fence();
 #pragma unroll
-    for (int d = 0; d < 5; d++) zr[d] = img[512 - lane - 64 * d];
+    for (int d = 0; d < 5; d++) zr[d] = xchg_ld(img, 512 - lane - 64 * d);
     wave_lds_fence();
 }
 
@@ -194,10 +194,10 @@ __device__ __forceinline__ void presplit_inv_pair(float2 ylo, float2 yhi, float2
 __device__ __forceinline__ void pair_return_lds(const float2 (&ret)[4], float2 *img, int lane, float2 (&y)[8])
 {
 #pragma unroll
-    for (int d = 0; d < 4; d++) img[512 - lane - 64 * d] = ret[d];
+    for (int d = 0; d < 4; d++) xchg_st(img, 512 - lane - 64 * d, ret[d]);
     wave_lds_fence();
 #pragma unroll
-    for (int d = 5; d < 8; d++) y[d] = img[lane + 64 * d];
+    for (int d = 5; d < 8; d++) y[d] = xchg_ld(img, lane + 64 * d);
     wave_lds_fence();
 }
 

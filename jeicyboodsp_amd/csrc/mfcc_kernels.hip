@@ -495,11 +495,11 @@ __device__ __forceinline__ void mfcc_x2_body(const short *__restrict__ src_a, co
         float2 za[5], zb[5];
         wave_lds_fence();
 #pragma unroll
-        for (int d = 3; d < 8; d++) { lds[0][lane + 64 * d] = va[d]; lds[1][lane + 64 * d] = vb[d]; }
+        for (int d = 3; d < 8; d++) { xchg_st(lds[0], lane + 64 * d, va[d]); xchg_st(lds[1], lane + 64 * d, vb[d]); }
         if (lane == 0) { lds[0][512] = va[0]; lds[1][512] = vb[0]; }
         wave_lds_fence();
 #pragma unroll
-        for (int d = 0; d < 5; d++) { za[d] = lds[0][512 - lane - 64 * d]; zb[d] = lds[1][512 - lane - 64 * d]; }
+        for (int d = 0; d < 5; d++) { za[d] = xchg_ld(lds[0], 512 - lane - 64 * d); zb[d] = xchg_ld(lds[1], 512 - lane - 64 * d); }
         wave_lds_fence();
         logmel[0][lane] = 0.f;                                       // (their home overlaps the image just read)
         logmel[1][lane] = 0.f;
@@ -708,12 +708,12 @@ __device__ __forceinline__ bool mfcc512_pair_mags(const float (&sa)[8], const fl
     wave_lds_fence();
     // bins k = lane + 64 d, d < 4 (0..255): mirrors Z[512 - k] are registers 4..7 of other lanes and Z[512] = Z[0]
 #pragma unroll
-    for (int d = 4; d < 8; d++) lds[lane + 64 * d] = v[d];
+    for (int d = 4; d < 8; d++) xchg_st(lds, lane + 64 * d, v[d]);
     if (lane == 0) lds[512] = v[0];
     wave_lds_fence();
 #pragma unroll
     for (int d = 0; d < 4; d++) {
-        const float2 zm = lds[512 - lane - 64 * d];
+        const float2 zm = xchg_ld(lds, 512 - lane - 64 * d);
         const float2 A = cadd_conj(v[d], zm), B = csub_conj_mj(v[d], zm);
         ma[d] = __builtin_amdgcn_sqrtf(A.x * A.x + A.y * A.y);   // hardware square root, 1 ulp (see mfcc_kernel)
         mb[d] = __builtin_amdgcn_sqrtf(B.x * B.x + B.y * B.y);

@@ -505,11 +505,11 @@ __global__ __launch_bounds__(64) void mvdr_pairs_kernel(const short *__restrict_
         wave_fft512_x2_staggered<false>(v, vr, lds2[0], lds2[1], lane, tw);
         // both channels' mirror operands in one round trip
 #pragma unroll
-        for (int d = 3; d < 8; d++) { lds2[0][lane + 64 * d] = v[d]; lds2[1][lane + 64 * d] = vr[d]; }
+        for (int d = 3; d < 8; d++) { xchg_st(lds2[0], lane + 64 * d, v[d]); xchg_st(lds2[1], lane + 64 * d, vr[d]); }
         if (lane == 0) { lds2[0][512] = v[0]; lds2[1][512] = vr[0]; }
         wave_lds_fence();
 #pragma unroll
-        for (int d = 0; d < 5; d++) { zr[d] = lds2[0][512 - lane - 64 * d]; zq[d] = lds2[1][512 - lane - 64 * d]; }
+        for (int d = 0; d < 5; d++) { zr[d] = xchg_ld(lds2[0], 512 - lane - 64 * d); zq[d] = xchg_ld(lds2[1], 512 - lane - 64 * d); }
         wave_lds_fence();
 #pragma unroll
         for (int d = 0; d < 5; d++) {
