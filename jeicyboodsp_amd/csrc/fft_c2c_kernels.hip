@@ -117,13 +117,17 @@ __device__ __forceinline__ void lds_fence_wave()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-constexpr int kFft512Lds = 8 * 73;                        // cd elements per wave (9,344 B)
+constexpr int kFft512Lds = 8 * 73;                        // cd elements per wave (9,344 B), padded layouts
+#ifndef JDSP_F64_SWIZZLE
+#define JDSP_F64_SWIZZLE 1          // 1: unpadded XOR layouts, 512 elements (8,192 B) per wave: see stft1024_f64_v2_kernel
+#endif
 
 template <bool INV>
-__global__ __launch_bounds__(64) void fft512_f64_kernel(const double2 *__restrict__ in, double2 *__restrict__ out, long batch,
+__global__ __launch_bounds__(64, JDSP_F64_SWIZZLE ? 5 : 4) void fft512_f64_kernel(const double2 *__restrict__ in, double2 *__restrict__ out, long batch,
                                                         const double2 *__restrict__ tw)
 {
-    __shared__ __attribute__((aligned(16))) cd lds[kFft512Lds];
+    // (JDSP_F64_SWIZZLE: the unpadded XOR layouts of stft1024_f64_v2_kernel, 8,192 B per wave, five waves per SIMD)
+    __shared__ __attribute__((aligned(16))) cd lds[JDSP_F64_SWIZZLE ? 512 : kFft512Lds];
     const int lane = threadIdx.x;
     const long per_xcd = (gridDim.x + 7) >> 3;            // XCD-aware order: neighbouring transforms share an XCD's L2
     const long t = (long)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
@@ -138,6 +142,16 @@ __global__ __launch_bounds__(64) void fft512_f64_kernel(const double2 *__restric
     cd_dft8<INV>(v);
 #pragma unroll
     for (int k = 1; k < 8; k++) v[k] = cd_mul(v[k], w512<INV>(tw, lane * k));
+#if JDSP_F64_SWIZZLE
+#pragma unroll
+    for (int k = 0; k < 8; k++) lds[k * 64 + (lane ^ (8 * ((k >> 1) & 1)))] = v[k];
+    lds_fence_wave();
+    {
+        const int k1 = lane >> 3, base = k1 * 64, g = 8 * ((k1 >> 1) & 1);
+#pragma unroll
+        for (int a = 0; a < 8; a++) v[a] = lds[base + (((lane & 7) + 8 * a) ^ g)];
+    }
+#else
 #pragma unroll
     for (int k = 0; k < 8; k++) lds[k * 72 + lane] = v[k];
     lds_fence_wave();
@@ -146,10 +160,24 @@ __global__ __launch_bounds__(64) void fft512_f64_kernel(const double2 *__restric
 #pragma unroll
         for (int a = 0; a < 8; a++) v[a] = lds[base + 8 * a];
     }
+#endif
     lds_fence_wave();
     cd_dft8<INV>(v);
 #pragma unroll
     for (int c = 1; c < 8; c++) v[c] = cd_mul(v[c], w512<INV>(tw, 8 * (lane & 7) * c));
+#if JDSP_F64_SWIZZLE
+    {
+        const int k1 = lane >> 3, b = lane & 7;
+#pragma unroll
+        for (int c = 0; c < 8; c++) lds[64 * k1 + ((8 * c + b) ^ k1)] = v[c];
+    }
+    lds_fence_wave();
+    {
+        const int k1 = lane & 7, c = lane >> 3;
+#pragma unroll
+        for (int b = 0; b < 8; b++) v[b] = lds[64 * k1 + ((8 * c + b) ^ k1)];
+    }
+#else
     {
         const int base = (lane >> 3) * 73 + (lane & 7);
 #pragma unroll
@@ -161,6 +189,7 @@ __global__ __launch_bounds__(64) void fft512_f64_kernel(const double2 *__restric
 #pragma unroll
         for (int b = 0; b < 8; b++) v[b] = lds[base + b];
     }
+#endif
     cd_dft8<INV>(v);
     typedef double f64x2 __attribute__((ext_vector_type(2)));
     f64x2 *dst = reinterpret_cast<f64x2 *>(out + t * 512 + lane);
@@ -340,12 +369,20 @@ __device__ __forceinline__ void cd_powers(const cd &b, cd (&p)[8])
 #endif
 // LOOP: a wave walks `run` > 1 frames (prefetch of the next frame, taken before this frame's stores); !LOOP: one frame per wave
 template <bool DW, bool LOOP>
-__global__ __launch_bounds__(64, 4) void stft1024_f64_v2_kernel(const short *__restrict__ pcm, long n_frames, long hop,
+__global__ __launch_bounds__(64, (JDSP_F64_SWIZZLE && !LOOP) ? 5 : 4) void stft1024_f64_v2_kernel(const short *__restrict__ pcm, long n_frames, long hop,
                                                                const double *__restrict__ table,
                                                                const double2 *__restrict__ tw, double2 *__restrict__ out,
                                                                int run)
 {
-    __shared__ __attribute__((aligned(16))) cd lds[kFft512Lds];
+    // JDSP_F64_SWIZZLE: an UNPADDED 512-element scratch (8,192 B per wave: twenty waves per CU = five per SIMD instead of
+    // the four that 9,344 B allow -- this kernel is bound by its store stream, and a fifth wave's stores in flight are
+    // what it is short of).  Conflict-free for the 16-byte accesses (ds_write_b128: 8 x 8 contiguous lanes; ds_read_b128:
+    // four groups of 16 lanes over 64 banks, MI355X_MICROARCH.md) by XOR instead of padding:
+    //   first exchange   element (row k, position l)  at 64 k + (l ^ 8 ((k >> 1) & 1))
+    //   second exchange  element (k1, c, b)           at 64 k1 + ((8 c + b) ^ k1)
+    //   natural image    Z[i] at i, and Z[512 - i] read at (512 - i) & 511 (slot 0 is Z[0] = Z[512])
+    constexpr bool SWZ = JDSP_F64_SWIZZLE && !LOOP;      // (the looping form is at its register limit without the XOR arithmetic)
+    __shared__ __attribute__((aligned(16))) cd lds[SWZ ? 512 : kFft512Lds];
     const int lane = threadIdx.x;
     // Frames in dispatch order: behind the read pass the PCM comes out of the Infinity Cache whichever XCD asks, and the
     // eight XCDs then write ONE moving 128 KB window of the output instead of eight streams 128 MiB apart
@@ -404,10 +441,17 @@ __global__ __launch_bounds__(64, 4) void stft1024_f64_v2_kernel(const short *__r
 #pragma unroll
             for (int k = 1; k < 8; k++) v[k] = cd_mul(v[k], p[k]);
         }
+        if constexpr (SWZ) {
 #pragma unroll
-        for (int k = 0; k < 8; k++) lds[k * 72 + lane] = v[k];
-        lds_fence_wave();
-        {
+            for (int k = 0; k < 8; k++) lds[k * 64 + (lane ^ (8 * ((k >> 1) & 1)))] = v[k];
+            lds_fence_wave();
+            const int k1 = lane >> 3, base = k1 * 64, g = 8 * ((k1 >> 1) & 1);
+#pragma unroll
+            for (int a = 0; a < 8; a++) v[a] = lds[base + (((lane & 7) + 8 * a) ^ g)];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; k++) lds[k * 72 + lane] = v[k];
+            lds_fence_wave();
             const int base = (lane >> 3) * 72 + (lane & 7);
 #pragma unroll
             for (int a = 0; a < 8; a++) v[a] = lds[base + 8 * a];
@@ -420,13 +464,23 @@ __global__ __launch_bounds__(64, 4) void stft1024_f64_v2_kernel(const short *__r
 #pragma unroll
             for (int c = 1; c < 8; c++) v[c] = cd_mul(v[c], p[c]);
         }
-        {
-            const int base = (lane >> 3) * 73 + (lane & 7);
+        if constexpr (SWZ) {
+            {
+                const int k1 = lane >> 3, b = lane & 7;
 #pragma unroll
-            for (int c = 0; c < 8; c++) lds[base + 8 * c] = v[c];
-        }
-        lds_fence_wave();
-        {
+                for (int c = 0; c < 8; c++) lds[64 * k1 + ((8 * c + b) ^ k1)] = v[c];
+            }
+            lds_fence_wave();
+            const int k1 = lane & 7, c = lane >> 3;
+#pragma unroll
+            for (int b = 0; b < 8; b++) v[b] = lds[64 * k1 + ((8 * c + b) ^ k1)];
+        } else {
+            {
+                const int base = (lane >> 3) * 73 + (lane & 7);
+#pragma unroll
+                for (int c = 0; c < 8; c++) lds[base + 8 * c] = v[c];
+            }
+            lds_fence_wave();
             const int base = (lane & 7) * 73 + (lane >> 3) * 8;
 #pragma unroll
             for (int b = 0; b < 8; b++) v[b] = lds[base + b];
@@ -440,7 +494,7 @@ __global__ __launch_bounds__(64, 4) void stft1024_f64_v2_kernel(const short *__r
         // profiles/r03_stft_f64.txt.)
 #pragma unroll
         for (int d = 0; d < 8; d++) lds[lane + 64 * d] = v[d];
-        if (lane == 0) lds[512] = v[0];
+        if constexpr (!SWZ) { if (lane == 0) lds[512] = v[0]; }
         lds_fence_wave();
         // the next frame's samples are taken BEFORE this frame's stores: vmcnt counts loads and stores together in issue
         // order and the loop's back edge waits for vmcnt(0), so taking them at the top of the next iteration waited for
@@ -457,7 +511,7 @@ __global__ __launch_bounds__(64, 4) void stft1024_f64_v2_kernel(const short *__r
         const cd w16[8] = {{1.0, 0.0}, {c1, -s1}, {h, -h}, {s1, -c1}, {0.0, -1.0}, {-s1, -c1}, {-h, -h}, {-c1, -s1}};
 #pragma unroll
         for (int d = 0; d < 8; d++) {
-            const cd zm = lds[512 - lane - 64 * d];
+            const cd zm = lds[SWZ ? ((512 - lane - 64 * d) & 511) : (512 - lane - 64 * d)];
             const cd w = d == 0 ? b3 : (d == 4 ? cd{b3.y, -b3.x} : cd_mul(b3, w16[d]));
             const cd e = {v[d].x + zm.x, v[d].y - zm.y};                  // Z + conj Zm
             const cd o = {v[d].y + zm.y, zm.x - v[d].x};                  // -j (Z - conj Zm)
