@@ -84,3 +84,17 @@ def test_product_never_touches_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp", ".c", "Makefile")):
                 txt = open(os.path.join(dp, f), errors="replace").read()
                 assert "oracle" not in txt.lower(), os.path.join(dp, f)
+
+
+def test_per_file_build_flags_name_existing_sources():
+    """csrc/build_flags.txt (per-file hipcc flags read by build() and tools/build_variant.sh): every entry names a source
+    that exists, and the flags are what the notes beside them say -- a renamed file must not silently lose its flags."""
+    import __graft_entry__ as g
+    flags = g.file_flags()
+    csrc = os.path.join(ROOT, "jeicyboodsp_amd", "csrc")
+    assert flags, "build_flags.txt parsed to nothing"
+    for name, fl in flags.items():
+        assert os.path.exists(os.path.join(csrc, name)), name
+        assert fl and all(f.startswith("-") for f in fl), (name, fl)
+    assert "-fno-slp-vectorize" in flags.get("mvdr_kernels.hip", [])
+    assert "-DJDSP_XCHG_UNPAIRED=0" in flags.get("stft_kernels.hip", [])
